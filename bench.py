@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on N GPUs of one node.
+
+Step = one batched forward negacyclic NTT (N=4096, SEAL moduli {60,49} bits) over a
+resident batch of `--polys` two-limb polynomials (default 4096 polys = 8192 limb-NTTs =
+256 MiB, past the Infinity Cache).  Weak scaling: every rank transforms its own batch,
+no collective on the data path.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_NTT = {4096: 65536, 8192: 131072}   # 2*N*8 B per limb-NTT
+
+
+def cpu_baseline(seconds=12.0):
+    """oracle (a port, not HEXL) forward NTT N=4096 on host cores, bounded sample"""
+    import numpy as np
+    from tests.oracle_binding import OracleCtx, A, uniform_mod
+    o = OracleCtx(4096, (60, 49), 0)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    n_polys = 64 * threads
+    a = np.stack([np.stack([uniform_mod(1 + l, 4096, q) for l, q in enumerate(o.q)])] * n_polys)
+    o.lib.mmo_ntt_forward_batch(o.p, A(a), n_polys, 2, threads)  # warm-up
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        o.lib.mmo_ntt_forward_batch(o.p, A(a), n_polys, 2, threads)
+        done += 2 * n_polys
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "NTT/s", "cores": threads, "kind": "port",
+            "sample": f"{done} forward limb-NTTs N=4096 (oracle Harvey/Shoup C, OpenMP) in {dt:.1f}s"}
+
+
+def timed(fn, steps, warmup, torch, dist, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    return wall, ev0.elapsed_time(ev1) / 1e3 / steps  # job wall seconds, per-launch device seconds
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--polys", type=int, default=4096, help="two-limb polynomials per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import openmm_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    ctx = openmm_amd.Context(4096, (60, 49), 0, device=local)
+    gen = torch.Generator(device="cuda").manual_seed(0x4D264D + rank)
+    qs = torch.tensor(ctx.q, dtype=torch.int64, device="cuda").view(1, 2, 1)
+    data = torch.randint(0, 2 ** 62, (args.polys, 2, 4096), dtype=torch.int64, device="cuda",
+                         generator=gen) % qs
+    ntts_per_step = args.polys * 2
+
+    wall, launch_s = timed(lambda: ctx.ntt_forward(data), args.steps, args.warmup, torch, dist, world)
+    value = world * ntts_per_step * args.steps / wall
+    achieved = ntts_per_step * BYTES_PER_NTT[4096] / launch_s
+
+    extra = {}
+    if rank == 0:
+        _, inv_s = timed(lambda: ctx.ntt_inverse(data), max(5, args.steps // 5), 2, torch, None, 1)
+        extra["intt4096_per_s"] = ntts_per_step / inv_s
+        c8 = openmm_amd.Context(8192, (60, 60, 60, 49), 0, device=local)
+        q8 = torch.tensor(c8.q, dtype=torch.int64, device="cuda").view(1, 4, 1)
+        d8 = torch.randint(0, 2 ** 62, (args.polys // 4, 4, 8192), dtype=torch.int64, device="cuda",
+                           generator=gen) % q8
+        _, f8 = timed(lambda: c8.ntt_forward(d8), max(5, args.steps // 5), 2, torch, None, 1)
+        _, i8 = timed(lambda: c8.ntt_inverse(d8), max(5, args.steps // 5), 2, torch, None, 1)
+        extra["ntt8192_per_s"] = d8.shape[0] * 4 / f8
+        extra["intt8192_per_s"] = d8.shape[0] * 4 / i8
+        extra["ntt8192_hbm_frac"] = d8.shape[0] * 4 * BYTES_PER_NTT[8192] / f8 / HBM_PEAK
+
+    if rank == 0:
+        line = {
+            "metric": "64-bit NTTs/sec (N=4096/8192) + ResNet50 HE-linear ms at 1/2/4/8 GPUs",
+            "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "batched forward negacyclic NTT N=4096, q={60,49}-bit SEAL moduli "
+                                   "(BASELINE.json configs[1])",
+                       "polys_per_gpu": args.polys, "limbs": 2, "ntts_per_step_per_gpu": ntts_per_step,
+                       "parallelism": f"independent batches x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "ntt_fwd_kernel<12>", "launch_us": launch_s * 1e6},
+            "extra": extra,
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

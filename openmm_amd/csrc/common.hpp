@@ -1,0 +1,103 @@
+// Shared declarations of libmm_hip: context layout, error plumbing, device-side
+// 64-bit modular arithmetic (Shoup / Barrett on VALU; no MFMA on this path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mm_hip.h"
+
+namespace mmh {
+using u64 = uint64_t;
+using u32 = uint32_t;
+
+constexpr int kMaxLimbs = 4;
+
+// One modulus as the kernels see it.  Twiddles are (w, floor(w*2^64/q)) pairs indexed
+// like SEAL's bit-reversed root-power tables: fwd[m + i] = psi^{bitrev(m+i)}.
+struct DevMod {
+  u64 q;
+  u64 barrett_hi, barrett_lo;  // floor(2^128 / q)
+  u64 ninv, ninv_sh;           // N^-1 mod q and its Shoup quotient
+  const ulonglong2 *fwd;       // length N
+  const ulonglong2 *inv;       // length N, inverses of fwd
+};
+
+void set_error(const std::string &msg);
+
+#define MMH_FAIL(code, msg)                                                    \
+  do {                                                                         \
+    ::mmh::set_error(std::string(__func__) + ": " + (msg));                    \
+    return (code);                                                             \
+  } while (0)
+
+#define MMH_HIP(expr)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) MMH_FAIL(MMH_ERR_INTERNAL, std::string(#expr " -> ") + hipGetErrorString(e_)); \
+  } while (0)
+
+#define MMH_REQUIRE(cond, code)                                                \
+  do {                                                                         \
+    if (!(cond)) MMH_FAIL(code, "requirement failed: " #cond);                 \
+  } while (0)
+
+// ---------------------------------------------------------------- device math
+__device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
+
+// x*w mod q in [0, 2q) for any 64-bit x, given wsh = floor(w*2^64/q)
+__device__ __forceinline__ u64 mul_shoup_lazy(u64 x, u64 w, u64 wsh, u64 q) {
+  return x * w - mulhi64(x, wsh) * q;
+}
+__device__ __forceinline__ u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+__device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 wsh, u64 q) {
+  return csub(mul_shoup_lazy(x, w, wsh, q), q);
+}
+__device__ __forceinline__ u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+__device__ __forceinline__ u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+
+// Barrett reduction of a 128-bit value (hi:lo) with ratio = floor(2^128/q); result in [0,q).
+// Same quotient estimate as SEAL util::barrett_reduce_128.
+__device__ __forceinline__ u64 barrett128(u64 hi, u64 lo, u64 q, u64 r_hi, u64 r_lo) {
+  // floor((hi:lo) * ratio / 2^128), dropping the lo*r_lo low word like SEAL does
+  u64 carry = mulhi64(lo, r_lo);
+  u64 t_lo = lo * r_hi, t_hi = mulhi64(lo, r_hi);
+  u64 s = t_lo + carry;
+  u64 tmp3 = t_hi + (s < t_lo);
+  u64 u_lo = hi * r_lo, u_hi = mulhi64(hi, r_lo);
+  u64 s2 = s + u_lo;
+  u64 c2 = u_hi + (s2 < s);
+  u64 quo = hi * r_hi + tmp3 + c2;
+  u64 r = lo - quo * q;
+  return csub(r, q);
+}
+__device__ __forceinline__ u64 mul_mod(u64 a, u64 b, const DevMod &m) {
+  return barrett128(mulhi64(a, b), a * b, m.q, m.barrett_hi, m.barrett_lo);
+}
+__device__ __forceinline__ u64 reduce64(u64 a, const DevMod &m) {
+  u64 r = a - mulhi64(a, m.barrett_hi) * m.q;
+  return csub(r, m.q);
+}
+}  // namespace mmh
+
+// The opaque context of the C ABI.
+struct mmh_ctx {
+  int device = 0;
+  size_t N = 0;
+  int logN = 0;
+  size_t L = 0;
+  mmh::u64 q[mmh::kMaxLimbs] = {0};
+  mmh::u64 psi[mmh::kMaxLimbs] = {0};
+  mmh::u64 t = 0;
+  bool t_pow2 = false;
+  bool batching = false;
+  mmh::u64 t_psi = 0;
+  mmh::u64 gamma = 0;
+  // device side: mods[0..L) = coefficient moduli, mods[L] = plain modulus when batching
+  mmh::DevMod *d_mods = nullptr;
+  mmh::DevMod h_mods[mmh::kMaxLimbs + 1];
+  std::vector<void *> allocs;
+};

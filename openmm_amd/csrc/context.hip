@@ -1,0 +1,165 @@
+// Context creation (host precomputation + upload), memory helpers, error text.
+#include "common.hpp"
+#include "host_math.hpp"
+
+namespace mmh {
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+static int upload(mmh_ctx *ctx, const void *src, size_t bytes, void **dst) {
+  MMH_HIP(hipMalloc(dst, bytes));
+  ctx->allocs.push_back(*dst);
+  MMH_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return MMH_OK;
+}
+
+// twiddle tables for modulus m with 2N-th root psi
+static int build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out) {
+  const size_t N = ctx->N;
+  std::vector<ulonglong2> fwd(N), inv(N);
+  const u64 ipsi = inv_mod(psi, m);
+  u64 p = 1, ip = 1;
+  for (size_t k = 0; k < N; ++k) {
+    const uint32_t r = bit_reverse((uint32_t)k, ctx->logN);
+    fwd[r] = make_ulonglong2(p, shoup(p, m));
+    inv[r] = make_ulonglong2(ip, shoup(ip, m));
+    p = mul_mod(p, psi, m);
+    ip = mul_mod(ip, ipsi, m);
+  }
+  out->q = m;
+  const u128 ratio = m & (m - 1) ? ~(u128)0 / m : (~(u128)0 / m) + 1;  // floor(2^128/m)
+  out->barrett_hi = (u64)(ratio >> 64);
+  out->barrett_lo = (u64)ratio;
+  out->ninv = inv_mod((u64)N % m, m);
+  out->ninv_sh = shoup(out->ninv, m);
+  void *d = nullptr;
+  int rc = upload(ctx, fwd.data(), N * sizeof(ulonglong2), &d);
+  if (rc) return rc;
+  out->fwd = (const ulonglong2 *)d;
+  rc = upload(ctx, inv.data(), N * sizeof(ulonglong2), &d);
+  if (rc) return rc;
+  out->inv = (const ulonglong2 *)d;
+  return MMH_OK;
+}
+}  // namespace mmh
+
+using namespace mmh;
+
+extern "C" const char *mmh_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int mmh_device_count(int *count) {
+  MMH_REQUIRE(count, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipGetDeviceCount(count));
+  return MMH_OK;
+}
+
+extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t L, uint64_t t,
+                              int device) {
+  MMH_REQUIRE(out && q, MMH_ERR_NULL_POINTER);
+  *out = nullptr;
+  const int logN = log2_exact(N);
+  MMH_REQUIRE(logN == 12 || logN == 13, MMH_ERR_CONFIG);
+  MMH_REQUIRE(L >= 1 && L <= (size_t)kMaxLimbs, MMH_ERR_CONFIG);
+  MMH_REQUIRE(t == 0 || L <= 2, MMH_ERR_CONFIG);
+  for (size_t l = 0; l < L; ++l) {
+    MMH_REQUIRE(bit_count(q[l]) <= 61 && is_prime(q[l]) && q[l] % (2 * N) == 1, MMH_ERR_INVALID_ARG);
+    MMH_REQUIRE(t == 0 || q[l] > t, MMH_ERR_INVALID_ARG);  // fast plain lift needs q_l > t
+    for (size_t k = 0; k < l; ++k) MMH_REQUIRE(q[k] != q[l], MMH_ERR_INVALID_ARG);
+  }
+  MMH_HIP(hipSetDevice(device));
+  mmh_ctx *ctx = new mmh_ctx();
+  ctx->device = device;
+  ctx->N = N;
+  ctx->logN = logN;
+  ctx->L = L;
+  ctx->t = t;
+  ctx->t_pow2 = t && !(t & (t - 1));
+  int rc = MMH_OK;
+  for (size_t l = 0; l < L && !rc; ++l) {
+    ctx->q[l] = q[l];
+    ctx->psi[l] = min_primitive_root(2 * N, q[l]);
+    rc = build_mod(ctx, q[l], ctx->psi[l], &ctx->h_mods[l]);
+  }
+  size_t n_mods = L;
+  if (!rc && t > 1 && is_prime(t) && t % (2 * N) == 1) {
+    ctx->batching = true;
+    ctx->t_psi = min_primitive_root(2 * N, t);
+    rc = build_mod(ctx, t, ctx->t_psi, &ctx->h_mods[L]);
+    n_mods = L + 1;
+  }
+  if (!rc && t > 1) {
+    auto g = primes_below(2 * N, 61, 2);
+    ctx->gamma = g.size() == 2 ? g[1] : 0;
+  }
+  if (!rc) {
+    void *d = nullptr;
+    rc = upload(ctx, ctx->h_mods, n_mods * sizeof(DevMod), &d);
+    ctx->d_mods = (DevMod *)d;
+  }
+  if (rc) {
+    mmh_ctx_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return MMH_OK;
+}
+
+extern "C" int mmh_ctx_create_bits(mmh_ctx **out, size_t N, const int *bits, size_t L, uint64_t t,
+                                   int device) {
+  MMH_REQUIRE(out && bits, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(L >= 1 && L <= (size_t)kMaxLimbs, MMH_ERR_CONFIG);
+  auto q = coeff_modulus(N, bits, L);
+  MMH_REQUIRE(q.size() == L, MMH_ERR_INVALID_ARG);
+  return mmh_ctx_create(out, N, q.data(), L, t, device);
+}
+
+extern "C" int mmh_ctx_destroy(mmh_ctx *ctx) {
+  if (!ctx) return MMH_OK;
+  (void)hipSetDevice(ctx->device);
+  for (void *p : ctx->allocs) (void)hipFree(p);
+  delete ctx;
+  return MMH_OK;
+}
+
+extern "C" int mmh_ctx_info(const mmh_ctx *ctx, size_t *N, size_t *L, uint64_t *q, uint64_t *psi,
+                            uint64_t *t, uint64_t *gamma) {
+  MMH_REQUIRE(ctx, MMH_ERR_NULL_POINTER);
+  if (N) *N = ctx->N;
+  if (L) *L = ctx->L;
+  for (size_t l = 0; l < ctx->L; ++l) {
+    if (q) q[l] = ctx->q[l];
+    if (psi) psi[l] = ctx->psi[l];
+  }
+  if (t) *t = ctx->t;
+  if (gamma) *gamma = ctx->gamma;
+  return MMH_OK;
+}
+
+extern "C" int mmh_malloc(void **d_ptr, size_t bytes) {
+  MMH_REQUIRE(d_ptr, MMH_ERR_NULL_POINTER);
+  if (hipMalloc(d_ptr, bytes) != hipSuccess) MMH_FAIL(MMH_ERR_MEMORY, "hipMalloc failed");
+  return MMH_OK;
+}
+extern "C" int mmh_free(void *d_ptr) {
+  MMH_HIP(hipFree(d_ptr));
+  return MMH_OK;
+}
+extern "C" int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream) {
+  MMH_REQUIRE((d_dst && src) || bytes == 0, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return MMH_OK;
+}
+extern "C" int mmh_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream) {
+  MMH_REQUIRE((dst && d_src) || bytes == 0, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return MMH_OK;
+}
+extern "C" int mmh_memset(void *d_dst, int value, size_t bytes, void *stream) {
+  MMH_REQUIRE(d_dst || bytes == 0, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+  return MMH_OK;
+}
+extern "C" int mmh_stream_sync(void *stream) {
+  MMH_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return MMH_OK;
+}

@@ -1,0 +1,150 @@
+"""ctypes binding of libmm_hip.so (C ABI: include/mm_hip.h).  No fallback path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmm_hip.so")
+
+CODE_NAMES = ["OK", "ERR_CONFIG", "ERR_NULL_POINTER", "ERR_DIM_MISMATCH", "ERR_SEAL_MEMORY",
+              "ERR_KEY_MISSING", "ERR_OUT_BOUND", "ERR_INVALID_ARG", "ERR_INTERNAL"]
+
+
+class MMHError(RuntimeError):
+    """Non-OK gemini::Code from the C ABI (include/gemini/core/types.h:30-40)."""
+
+    def __init__(self, code, text):
+        self.code = code
+        name = CODE_NAMES[code] if 0 <= code < len(CODE_NAMES) else str(code)
+        super().__init__(f"{name}: {text}")
+
+
+_lib = None
+_vp, _sz, _u64, _int = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
+
+# name -> argtypes; every function returns int (gemini::Code) unless listed in _RESTYPE
+SIGNATURES = {
+    "mmh_device_count": [C.POINTER(_int)],
+    "mmh_ctx_create": [C.POINTER(_vp), _sz, C.POINTER(_u64), _sz, _u64, _int],
+    "mmh_ctx_create_bits": [C.POINTER(_vp), _sz, C.POINTER(_int), _sz, _u64, _int],
+    "mmh_ctx_destroy": [_vp],
+    "mmh_ctx_info": [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_u64), C.POINTER(_u64),
+                     C.POINTER(_u64), C.POINTER(_u64)],
+    "mmh_malloc": [C.POINTER(_vp), _sz],
+    "mmh_free": [_vp],
+    "mmh_memcpy_h2d": [_vp, _vp, _sz, _vp],
+    "mmh_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "mmh_memset": [_vp, _int, _sz, _vp],
+    "mmh_stream_sync": [_vp],
+    "mmh_ntt_forward": [_vp, _vp, _sz, _sz, _vp],
+    "mmh_ntt_inverse": [_vp, _vp, _sz, _sz, _vp],
+    "mmh_ntt_forward_t": [_vp, _vp, _sz, _vp],
+    "mmh_ntt_inverse_t": [_vp, _vp, _sz, _vp],
+}
+
+
+def load_library():
+    """Load libmm_hip.so; raise loudly when it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C openmm_amd/csrc` "
+            "(or __graft_entry__.build()). openmm_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.mmh_last_error.restype = C.c_char_p
+    lib.mmh_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise MMHError(code, load_library().mmh_last_error().decode())
+
+
+def _stream_ptr():
+    import torch
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Device pointer of a contiguous torch CUDA tensor (any 8-byte integer dtype)."""
+    assert t.is_cuda and t.is_contiguous()
+    return _vp(t.data_ptr())
+
+
+def to_device(arr, device="cuda:0"):
+    """numpy uint64 array -> torch int64 CUDA tensor with the same bits."""
+    import torch
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    """torch int64 tensor -> numpy uint64 array with the same bits."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class Context:
+    """seal::SEALContext stand-in for the hot path (cheetah-api.cpp:95-105,:151-162)."""
+
+    def __init__(self, N=4096, bits=(60, 49), t=0, q=None, device=0):
+        self.lib = load_library()
+        self.handle = _vp()
+        if q is not None:
+            arr = (_u64 * len(q))(*q)
+            check(self.lib.mmh_ctx_create(C.byref(self.handle), N, arr, len(q), t, device))
+        else:
+            arr = (_int * len(bits))(*bits)
+            check(self.lib.mmh_ctx_create_bits(C.byref(self.handle), N, arr, len(bits), t, device))
+        n, l, tt, g = _sz(), _sz(), _u64(), _u64()
+        qs, psis = (_u64 * 4)(), (_u64 * 4)()
+        check(self.lib.mmh_ctx_info(self.handle, C.byref(n), C.byref(l), qs, psis, C.byref(tt),
+                                    C.byref(g)))
+        self.N, self.L, self.t, self.gamma = n.value, l.value, tt.value, g.value
+        self.q = [int(qs[i]) for i in range(self.L)]
+        self.psi = [int(psis[i]) for i in range(self.L)]
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            self.lib.mmh_ctx_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # seal::util::ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey, batched, in place
+    def ntt_forward(self, polys, limbs=None):
+        limbs = self.L if limbs is None else limbs
+        assert polys.numel() % (limbs * self.N) == 0
+        check(self.lib.mmh_ntt_forward(self.handle, dptr(polys), polys.numel() // (limbs * self.N),
+                                       limbs, _stream_ptr()))
+        return polys
+
+    def ntt_inverse(self, polys, limbs=None):
+        limbs = self.L if limbs is None else limbs
+        assert polys.numel() % (limbs * self.N) == 0
+        check(self.lib.mmh_ntt_inverse(self.handle, dptr(polys), polys.numel() // (limbs * self.N),
+                                       limbs, _stream_ptr()))
+        return polys
+
+    def ntt_forward_t(self, polys):
+        check(self.lib.mmh_ntt_forward_t(self.handle, dptr(polys), polys.numel() // self.N,
+                                         _stream_ptr()))
+        return polys
+
+    def ntt_inverse_t(self, polys):
+        check(self.lib.mmh_ntt_inverse_t(self.handle, dptr(polys), polys.numel() // self.N,
+                                         _stream_ptr()))
+        return polys

@@ -693,3 +693,15 @@ uint64_t mmo_modulo_mult(uint64_t a, uint64_t b, uint64_t mod) { /* utils.hpp:35
 void mmo_bole_cross_term(uint64_t *out, const uint64_t *x, const uint64_t *y, size_t n, uint64_t p) {
   for (size_t i = 0; i < n; i++) out[i] = (out[i] + mmo_modulo_mult(x[i], y[i], p)) % p;
 }
+
+/* ------------------------------------------------- CPU baseline batches */
+void mmo_ntt_forward_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads) {
+  long total = (long)(n_polys * limbs);
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long b = 0; b < total; b++) fwd(c, (size_t)b % limbs, polys + (size_t)b * c->N);
+}
+void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads) {
+  long total = (long)(n_polys * limbs);
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long b = 0; b < total; b++) inv(c, (size_t)b % limbs, polys + (size_t)b * c->N);
+}

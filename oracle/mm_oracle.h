@@ -171,6 +171,10 @@ void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, si
 uint64_t mmo_modulo_mult(uint64_t a, uint64_t b, uint64_t mod);
 void mmo_bole_cross_term(uint64_t *out, const uint64_t *x, const uint64_t *y, size_t n, uint64_t p);
 
+/* ---- timed CPU baseline helpers (bench.py cpu_baseline leg): OpenMP over independent polys */
+void mmo_ntt_forward_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
+void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
+
 #ifdef __cplusplus
 }
 #endif
