@@ -20,10 +20,12 @@ constexpr int kMaxLimbs = 4;
 // like SEAL's bit-reversed root-power tables: fwd[m + i] = psi^{bitrev(m+i)}.
 struct DevMod {
   u64 q;
+  u64 nq;                      // 2^64 - q
   u64 barrett_hi, barrett_lo;  // floor(2^128 / q)
   u64 ninv, ninv_sh;           // N^-1 mod q and its Shoup quotient
   const ulonglong2 *fwd;       // length N
   const ulonglong2 *inv;       // length N, inverses of fwd
+  u64 tw_offset;               // fwd = tables + tw_offset, inv = fwd + N (one allocation per context)
 };
 
 void set_error(const std::string &msg);
@@ -53,6 +55,50 @@ __device__ __forceinline__ u64 mul_shoup_lazy(u64 x, u64 w, u64 wsh, u64 q) {
   return x * w - mulhi64(x, wsh) * q;
 }
 __device__ __forceinline__ u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+
+// v_mad_u64_u32 is the cheapest wide multiply on gfx950 (measured 4 cycles per wave64 against
+// 8 for v_mul_lo_u32 / v_mul_hi_u32, profiles/r01_a_valu_probe.txt), and chains of it need no
+// register shuffling because the 64-bit result feeds the next addend directly.  hipcc narrows a
+// C-level (u64)a*b+c whose high half is unused back to v_mul_lo_u32, hence the asm form.
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) {
+  u64 d, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ u64 mul32(u32 a, u32 b) {
+  u64 d, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+
+// low 32 bits of a0*b0 + a1*b1 + a2*b2 + a3*b3 as one dependent chain of four mads (one asm
+// statement so that hipcc pads it once, not after every instruction)
+__device__ __forceinline__ u32 dot4_lo(u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3) {
+  u64 d, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\t"
+      "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t"
+      "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t"
+      "v_mad_u64_u32 %0, %1, %8, %9, %0"
+      : "=&v"(d), "=&s"(carry)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+  return (u32)d;
+}
+
+// x*w mod q in [0, 3q) for any 64-bit x: Shoup whose high product drops only the low partial
+// product x0*s0 (quotient short by at most 1).  nq = 2^64 - q.  9 mads.
+__device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wsh, u64 nq) {
+  const u32 x0 = lo32(x), x1 = hi32(x), s0 = lo32(wsh), s1 = hi32(wsh);
+  const u64 m1 = (u64)x1 * s0;
+  const u64 m2 = (u64)x0 * s1 + m1;
+  const u64 c = (m2 >> 32) | ((u64)(m2 < m1) << 32);
+  const u64 h = (u64)x1 * s1 + c;
+  const u32 h0 = lo32(h), h1 = hi32(h);
+  const u64 t = (u64)h0 * lo32(nq) + (u64)x0 * lo32(w);
+  const u32 acc = dot4_lo(x0, hi32(w), x1, lo32(w), h0, hi32(nq), h1, lo32(nq));
+  return t + ((u64)acc << 32);
+}
 __device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 wsh, u64 q) {
   return csub(mul_shoup_lazy(x, w, wsh, q), q);
 }
@@ -98,6 +144,7 @@ struct mmh_ctx {
   mmh::u64 gamma = 0;
   // device side: mods[0..L) = coefficient moduli, mods[L] = plain modulus when batching
   mmh::DevMod *d_mods = nullptr;
+  ulonglong2 *d_tables = nullptr;  // all twiddle tables, [(fwd,inv) per modulus][N]
   mmh::DevMod h_mods[mmh::kMaxLimbs + 1];
   std::vector<void *> allocs;
 };

@@ -13,10 +13,11 @@ static int upload(mmh_ctx *ctx, const void *src, size_t bytes, void **dst) {
   return MMH_OK;
 }
 
-// twiddle tables for modulus m with 2N-th root psi
-static int build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out) {
-  const size_t N = ctx->N;
-  std::vector<ulonglong2> fwd(N), inv(N);
+// twiddle tables for modulus m with 2N-th root psi, appended to `tables`
+static void build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out, std::vector<ulonglong2> &tables) {
+  const size_t N = ctx->N, base = tables.size();
+  tables.resize(base + 2 * N);
+  ulonglong2 *fwd = tables.data() + base, *inv = fwd + N;
   const u64 ipsi = inv_mod(psi, m);
   u64 p = 1, ip = 1;
   for (size_t k = 0; k < N; ++k) {
@@ -27,19 +28,13 @@ static int build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out) {
     ip = mul_mod(ip, ipsi, m);
   }
   out->q = m;
+  out->nq = 0 - m;
   const u128 ratio = m & (m - 1) ? ~(u128)0 / m : (~(u128)0 / m) + 1;  // floor(2^128/m)
   out->barrett_hi = (u64)(ratio >> 64);
   out->barrett_lo = (u64)ratio;
   out->ninv = inv_mod((u64)N % m, m);
   out->ninv_sh = shoup(out->ninv, m);
-  void *d = nullptr;
-  int rc = upload(ctx, fwd.data(), N * sizeof(ulonglong2), &d);
-  if (rc) return rc;
-  out->fwd = (const ulonglong2 *)d;
-  rc = upload(ctx, inv.data(), N * sizeof(ulonglong2), &d);
-  if (rc) return rc;
-  out->inv = (const ulonglong2 *)d;
-  return MMH_OK;
+  out->tw_offset = base;
 }
 }  // namespace mmh
 
@@ -75,17 +70,27 @@ extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t
   ctx->t = t;
   ctx->t_pow2 = t && !(t & (t - 1));
   int rc = MMH_OK;
-  for (size_t l = 0; l < L && !rc; ++l) {
+  std::vector<ulonglong2> tables;
+  for (size_t l = 0; l < L; ++l) {
     ctx->q[l] = q[l];
     ctx->psi[l] = min_primitive_root(2 * N, q[l]);
-    rc = build_mod(ctx, q[l], ctx->psi[l], &ctx->h_mods[l]);
+    build_mod(ctx, q[l], ctx->psi[l], &ctx->h_mods[l], tables);
   }
   size_t n_mods = L;
-  if (!rc && t > 1 && is_prime(t) && t % (2 * N) == 1) {
+  if (t > 1 && is_prime(t) && t % (2 * N) == 1) {
     ctx->batching = true;
     ctx->t_psi = min_primitive_root(2 * N, t);
-    rc = build_mod(ctx, t, ctx->t_psi, &ctx->h_mods[L]);
+    build_mod(ctx, t, ctx->t_psi, &ctx->h_mods[L], tables);
     n_mods = L + 1;
+  }
+  {
+    void *d = nullptr;
+    rc = upload(ctx, tables.data(), tables.size() * sizeof(ulonglong2), &d);
+    ctx->d_tables = (ulonglong2 *)d;
+    for (size_t i = 0; i < n_mods && !rc; ++i) {
+      ctx->h_mods[i].fwd = ctx->d_tables + ctx->h_mods[i].tw_offset;
+      ctx->h_mods[i].inv = ctx->h_mods[i].fwd + N;
+    }
   }
   if (!rc && t > 1) {
     auto g = primes_below(2 * N, 61, 2);

@@ -5,7 +5,7 @@
 //   pass B  radix-16 on 16-element groups of stride 16 exchanged through LDS,
 //   pass C  radix-16 on 16 consecutive elements, then a coalesced 16-B/lane store.
 // 64-bit Harvey butterflies with Shoup twiddles (w, floor(w 2^64/q)) on VALU; values stay
-// lazily reduced in [0,4q) (forward) / [0,2q) (inverse) and are corrected once at the end,
+// lazily reduced in [0,8q) and are corrected once at the end,
 // so the visible result equals seal::util::ntt_negacyclic_harvey /
 // inverse_ntt_negacyclic_harvey (hom_conv2d_ss.cc:306,315,333): bit-reversed order,
 // fully reduced.
@@ -23,7 +23,7 @@ __device__ __forceinline__ int pad(int j) { return j + (j >> 4); }
 // k + 2^(R-1-u) and uses twiddle fwd[2^(S0+u) + (jhi<<u) + (k >> (R-u))].
 template <int R, int S0>
 __device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__restrict__ tw,
-                                          u32 jhi, u64 q, u64 q2) {
+                                          u32 jhi, u64 nq, u64 q4) {
 #pragma unroll
   for (int u = 0; u < R; ++u) {
     const int half = 1 << (R - 1 - u);
@@ -35,10 +35,10 @@ __device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__
       for (int i = 0; i < half; ++i) {
         const int k0 = b * 2 * half + i, k1 = k0 + half;
         u64 X = x[k0];
-        X -= (X >= q2) ? q2 : 0;
-        const u64 T = mul_shoup_lazy(x[k1], w.x, w.y, q);
+        X -= (X >= q4) ? q4 : 0;
+        const u64 T = mul_shoup_lazy4(x[k1], w.x, w.y, nq);
         x[k0] = X + T;
-        x[k1] = X + q2 - T;
+        x[k1] = X + q4 - T;
       }
     }
   }
@@ -47,7 +47,7 @@ __device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__
 // The same stages run backwards (Gentleman-Sande) with the inverse twiddles.
 template <int R, int S0>
 __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 *__restrict__ tw,
-                                          u32 jhi, u64 q, u64 q2) {
+                                          u32 jhi, u64 nq, u64 q4) {
 #pragma unroll
   for (int u = R - 1; u >= 0; --u) {
     const int half = 1 << (R - 1 - u);
@@ -60,9 +60,9 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 *__
         const int k0 = b * 2 * half + i, k1 = k0 + half;
         const u64 X = x[k0], Y = x[k1];
         u64 s = X + Y;
-        s -= (s >= q2) ? q2 : 0;
+        s -= (s >= q4) ? q4 : 0;
         x[k0] = s;
-        x[k1] = mul_shoup_lazy(X + q2 - Y, w.x, w.y, q);
+        x[k1] = mul_shoup_lazy4(X + q4 - Y, w.x, w.y, nq);
       }
     }
   }
@@ -70,21 +70,22 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 *__
 
 template <int LOGN>
 __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
-                                                      const DevMod *__restrict__ mods, int limbs,
-                                                      int mod_base) {
+                                                      const DevMod *__restrict__ mods,
+                                                      const ulonglong2 *__restrict__ tables,
+                                                      int limbs, int mod_base) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
   const DevMod &M = mods[mod_base + blockIdx.x % limbs];
-  const u64 q = M.q, q2 = 2 * q;
-  const ulonglong2 *__restrict__ tw = M.fwd;
+  const u64 q = M.q, q2 = 2 * q, q4 = 4 * q, nq = M.nq;
+  const ulonglong2 *__restrict__ tw = tables + M.tw_offset;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
   {
     u64 x[EA];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
-    fwd_radix<RA, 0>(x, tw, 0, q, q2);
+    fwd_radix<RA, 0>(x, tw, 0, nq, q4);
 #pragma unroll
     for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = x[k];
   }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
-    fwd_radix<4, RA>(x, tw, jhi, q, q2);
+    fwd_radix<4, RA>(x, tw, jhi, nq, q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
   }
@@ -106,10 +107,11 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
-    fwd_radix<4, RA + 4>(x, tw, g, q, q2);
+    fwd_radix<4, RA + 4>(x, tw, g, nq, q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       u64 v = x[k];
+      v -= (v >= q4) ? q4 : 0;
       v -= (v >= q2) ? q2 : 0;
       v -= (v >= q) ? q : 0;
       lds[17 * g + k] = v;
@@ -126,14 +128,15 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
 
 template <int LOGN>
 __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
-                                                      const DevMod *__restrict__ mods, int limbs,
-                                                      int mod_base) {
+                                                      const DevMod *__restrict__ mods,
+                                                      const ulonglong2 *__restrict__ tables,
+                                                      int limbs, int mod_base) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
   const DevMod &M = mods[mod_base + blockIdx.x % limbs];
-  const u64 q = M.q, q2 = 2 * q;
-  const ulonglong2 *__restrict__ tw = M.inv;
+  const u64 q = M.q, q2 = 2 * q, q4 = 4 * q, nq = M.nq;
+  const ulonglong2 *__restrict__ tw = tables + M.tw_offset + N;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
   const ulonglong2 *__restrict__ in = reinterpret_cast<const ulonglong2 *>(a);
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
-    inv_radix<4, RA + 4>(x, tw, g, q, q2);
+    inv_radix<4, RA + 4>(x, tw, g, nq, q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[17 * g + k] = x[k];
   }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
-    inv_radix<4, RA>(x, tw, jhi, q, q2);
+    inv_radix<4, RA>(x, tw, jhi, nq, q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
   }
@@ -171,10 +174,15 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[EA];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
-    inv_radix<RA, 0>(x, tw, 0, q, q2);
+    inv_radix<RA, 0>(x, tw, 0, nq, q4);
     const u64 ninv = M.ninv, ninv_sh = M.ninv_sh;
 #pragma unroll
-    for (int k = 0; k < EA; ++k) a[k * 256 + t] = mul_shoup(x[k], ninv, ninv_sh, q);
+    for (int k = 0; k < EA; ++k) {
+      u64 v = mul_shoup_lazy4(x[k], ninv, ninv_sh, nq);
+      v -= (v >= q2) ? q2 : 0;
+      v -= (v >= q) ? q : 0;
+      a[k * 256 + t] = v;
+    }
   }
 }
 
@@ -184,14 +192,14 @@ static constexpr size_t lds_bytes() {
 }
 
 template <int LOGN>
-static int launch(bool inverse, u64 *d, const DevMod *mods, size_t blocks, int limbs, int mod_base,
-                  hipStream_t s) {
+static int launch(bool inverse, u64 *d, const DevMod *mods, const ulonglong2 *tables, size_t blocks,
+                  int limbs, int mod_base, hipStream_t s) {
   auto kern = inverse ? ntt_inv_kernel<LOGN> : ntt_fwd_kernel<LOGN>;
   if (lds_bytes<LOGN>() > 48 * 1024)  // per device and cheap: set on every launch
     MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<LOGN>()));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes<LOGN>(), s, d, mods, limbs,
-                     mod_base);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes<LOGN>(), s, d, mods, tables,
+                     limbs, mod_base);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
@@ -202,8 +210,8 @@ int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys,
   if (blocks == 0) return MMH_OK;
   MMH_REQUIRE(blocks <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
   switch (ctx->logN) {
-    case 12: return launch<12>(inverse, d_polys, ctx->d_mods, blocks, limbs, mod_base, s);
-    case 13: return launch<13>(inverse, d_polys, ctx->d_mods, blocks, limbs, mod_base, s);
+    case 12: return launch<12>(inverse, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
+    case 13: return launch<13>(inverse, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
     default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
   }
 }
