@@ -75,6 +75,105 @@ int mmh_ntt_inverse(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_
 int mmh_ntt_forward_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, void *stream);
 int mmh_ntt_inverse_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, void *stream);
 
+/* =====================================================================================
+ * BFV arithmetic on batches of ciphertexts / plaintexts (BFV contexts only: t >= 2, L <= 2).
+ * lv selects the level: 0 = first level (all L limbs), 1 = last level ({q0} only,
+ * context.last_parms_id() in the reference).  A ciphertext is [2][limbs(lv)][N], a
+ * coefficient-form plaintext is [N] (values < t), both in coefficient (non-NTT) form unless
+ * a name says ntt.
+ * ===================================================================================== */
+
+/* c0 += round(Q m/t) (sub = 0) or c0 -= (sub = 1) for n ciphertexts and n plaintexts.
+ * seal::Evaluator::add_plain / add_plain_inplace / sub_plain_inplace
+ * (hom_conv2d_ss.cc:658, :79; hom_bn_ss.cc:264, :355).  d_out may equal d_cts. */
+int mmh_add_plain(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, const uint64_t *d_pts, size_t n,
+                  int sub, uint64_t *d_out, void *stream);
+
+/* "fast plain lift" of n plaintexts into RNS form followed by the forward NTT:
+ * d_out[n][limbs][N].  First half of seal::Evaluator::multiply_plain for non-NTT BFV
+ * (hom_conv2d_ss.cc:610,613); exposed so that static weights can be transformed once. */
+int mmh_plain_lift_ntt(const mmh_ctx *ctx, int lv, const uint64_t *d_pts, size_t n, uint64_t *d_out,
+                       void *stream);
+
+/* Dyadic multiply-accumulate on NTT-form operands:
+ *   out[o1][o2] = sum_{k<K} ct[k*ct_sk + o2*ct_s2] (.) pt[o1*pt_s1 + k*pt_sk + o2*pt_s2]
+ * for o1 < n_o1, o2 < n_o2; out is [n_o1*n_o2] ciphertexts in NTT form, fully reduced.
+ * seal::util::dyadic_product_coeffmod + add_poly_coeffmod as reached from
+ * conv2DOneFilter (hom_conv2d_ss.cc:597-616), matVecMul (hom_fc_ss.cc:443-456) and
+ * bole/bn (hom_bn_ss.cc:264-268, :304-306). */
+int mmh_dyadic_mac(const mmh_ctx *ctx, int lv, const uint64_t *d_cts_ntt, size_t n_cts,
+                   const uint64_t *d_pts_ntt, size_t n_pts, size_t n_o1, size_t n_o2, size_t K,
+                   size_t ct_sk, size_t ct_s2, size_t pt_s1, size_t pt_sk, size_t pt_s2,
+                   uint64_t *d_out_ntt, void *stream);
+
+/* The whole multiply_plain + add_inplace schedule on coefficient-form inputs and outputs:
+ * NTT(cts) once, lift+NTT(pts) once, dyadic MAC, one inverse NTT per output polynomial.
+ * Bit-identical to the reference's per-term multiply_plain/add_inplace loop because every
+ * step is exact modulo q_l.  Workspace is taken from the stream-ordered pool. */
+int mmh_mul_plain_acc(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, size_t n_cts,
+                      const uint64_t *d_pts, size_t n_pts, size_t n_o1, size_t n_o2, size_t K,
+                      size_t ct_sk, size_t ct_s2, size_t pt_s1, size_t pt_sk, size_t pt_s2,
+                      uint64_t *d_out, void *stream);
+
+/* a += b on n ciphertexts (seal::Evaluator::add_inplace, hom_conv2d_ss.cc:386,611) */
+int mmh_ct_add(const mmh_ctx *ctx, int lv, uint64_t *d_a, const uint64_t *d_b, size_t n, void *stream);
+
+/* first level -> last level: RNSTool::divide_and_round_q_last per polynomial
+ * (seal::Evaluator::mod_switch_to_inplace, hom_conv2d_ss.cc:382,408; hom_bn_ss.cc:269,307).
+ * d_in [n][2][L][N] -> d_out [n][2][1][N]. */
+int mmh_mod_switch_to_last(const mmh_ctx *ctx, const uint64_t *d_in, size_t n, uint64_t *d_out, void *stream);
+
+/* Public-key encryption of zero with injected randomness, coefficient-form output:
+ * asymmetric_encrypt_zero (hom_conv2d_ss.cc:275-340).  d_pk_ntt [2][limbs(lv)][N] in NTT form,
+ * d_u [n][N] ternary in {-1,0,1}, d_e0 / d_e1 [n][N] signed noise (d_e0 may be NULL: the
+ * USE_APPROX_RESHARE build skips e0, :323-328).  d_out [n][2][limbs][N]. */
+int mmh_encrypt_zero_asym(const mmh_ctx *ctx, int lv, const uint64_t *d_pk_ntt, const int64_t *d_u,
+                          const int64_t *d_e0, const int64_t *d_e1, size_t n, uint64_t *d_out, void *stream);
+
+/* Secret-key encryption with injected randomness: c1 = a, c0 = -(a s + e) + round(Q m/t).
+ * seal::Encryptor::encrypt_symmetric (hom_conv2d_ss.cc:516, hom_fc_ss.cc:257, hom_bn_ss.cc:180).
+ * d_sk_ntt [limbs][N] NTT form; d_a [n][limbs][N] uniform < q_l; d_e [n][N] signed;
+ * d_pts [n][N] or NULL (encrypt_zero_symmetric, hom_bn_ss.cc:535). */
+int mmh_encrypt_symmetric(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt, const uint64_t *d_a,
+                          const int64_t *d_e, const uint64_t *d_pts, size_t n, uint64_t *d_out, void *stream);
+
+/* Public key from injected randomness: pk = (-(a s + e), a) in NTT form at the first level
+ * (seal::KeyGenerator::create_public_key, cheetah-api.cpp:113,167). d_a_ntt [L][N], d_e [N]. */
+int mmh_make_public_key(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_a_ntt,
+                        const int64_t *d_e, uint64_t *d_pk_ntt, void *stream);
+
+/* BFV decryption of n ciphertexts to n plaintexts [n][N] (coefficients < t, NOT trimmed of
+ * leading zeros): seal::Decryptor::decrypt (hom_conv2d_ss.cc:906, hom_fc_ss.cc:590,
+ * hom_bn_ss.cc:389) = dot product with sk, then RNSTool::decrypt_scale_and_round in the
+ * patched form (patch/SEAL.patch:125-175). */
+int mmh_decrypt(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n,
+                uint64_t *d_pts, void *stream);
+
+/* RNSTool::decrypt_scale_and_round on gathered coefficients: out[k][j] =
+ * scale_and_round( polys[k][.][targets[j]] ), polys [n][limbs][N], targets [n_targets] shared
+ * by all n (approximate re-sharing, sample_random_mask hom_conv2d_ss.cc:209-221).
+ * d_targets = NULL means all N coefficients in order. */
+int mmh_scale_and_round(const mmh_ctx *ctx, int lv, const uint64_t *d_polys, size_t n,
+                        const uint32_t *d_targets, size_t n_targets, uint64_t *d_out, void *stream);
+
+/* ct.c0 -= r for an RNS-form polynomial r [n][limbs][N] (internal::sub_poly_inplace with a
+ * parms_id-carrying plaintext, hom_conv2d_ss.cc:83-103) */
+int mmh_sub_rns_poly(const mmh_ctx *ctx, int lv, uint64_t *d_cts, const uint64_t *d_r, size_t n, void *stream);
+
+/* truncate_for_decryption (hom_conv2d_ss.cc:392-441) fused with remove_unused_coeffs
+ * (:108-140): on n last-level ciphertexts, c0 &= mask0, c1 &= mask1, and when d_keep != NULL
+ * every coefficient i with keep[(k % keep_period)*N + i] == 0 is zeroed in c0 (the reference
+ * walks ct.data(0) only, so c1 keeps all its coefficients).
+ * Masks: mmh_truncate_masks. */
+int mmh_truncate_masks(const mmh_ctx *ctx, uint64_t *mask0, uint64_t *mask1);
+int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t n, const uint8_t *d_keep,
+                          size_t keep_period, void *stream);
+
+/* seal::BatchEncoder::encode / decode on n vectors of N slots (hom_bn_ss.cc:179,225,354,390):
+ * encode reduces inputs mod t first (ring_to_field outputs are only congruent). */
+int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts, void *stream);
+int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

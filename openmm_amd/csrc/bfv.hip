@@ -1,0 +1,615 @@
+// BFV arithmetic on batches: plain scaling, plaintext multiply-accumulate, mod-switch,
+// encryption with injected randomness, decryption (BEHZ scale-and-round), truncation,
+// BatchEncoder.  All kernels are element-wise over coefficients (HBM-bound streaming) and
+// use the batched NTT of ntt.hip for the transforms.  Reference call sites: include/mm_hip.h.
+#include "common.hpp"
+
+namespace mmh {
+int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
+                 int mod_base, hipStream_t s);
+
+// stream-ordered scratch buffer
+struct StreamBuf {
+  void *p = nullptr;
+  hipStream_t s;
+  explicit StreamBuf(hipStream_t st) : s(st) {}
+  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 1, s); }
+  ~StreamBuf() {
+    if (p) (void)hipFreeAsync(p, s);
+  }
+  template <class T>
+  T *as() { return reinterpret_cast<T *>(p); }
+};
+
+__device__ __forceinline__ u64 reduce128(u64 hi, u64 lo, const ModC &m) {
+  return barrett128(hi, lo, m.q, m.barrett_hi, m.barrett_lo);
+}
+__device__ __forceinline__ u64 mulmod_c(u64 a, u64 b, const ModC &m) {
+  return reduce128(mulhi64(a, b), a * b, m);
+}
+// Barrett for sums of products that may approach 2^128: two corrections
+__device__ __forceinline__ u64 reduce128_wide(u64 hi, u64 lo, const DevMod &m) {
+  return csub(barrett128(hi, lo, m.q, m.barrett_hi, m.barrett_lo), m.q);
+}
+__device__ __forceinline__ u64 signed_to_mod(int64_t v, u64 q) {
+  return v >= 0 ? (u64)v : q - (u64)(-v);
+}
+
+// round(Q m / t) mod q_l, SEAL multiply_add_plain_with_scaling_variant
+__device__ __forceinline__ u64 scale_fix(u64 m, const BfvConsts &b, const LevelConsts &c) {
+  u64 lo = m * c.q_mod_t, hi = mulhi64(m, c.q_mod_t);
+  lo += b.thr;
+  hi += lo < b.thr;
+  if (b.t_log2 >= 0) return b.t_log2 == 0 ? lo : (lo >> b.t_log2) | (hi << (64 - b.t_log2));
+  const u64 r = reduce128(hi, lo, b.t);
+  return (lo - r) * b.t_inv64;  // exact division of a multiple of the odd t
+}
+__device__ __forceinline__ u64 scaled_plain(u64 m, u64 fix, u64 delta, const DevMod &q) {
+  u64 lo = m * delta, hi = mulhi64(m, delta);
+  lo += fix;
+  hi += lo < fix;
+  return barrett128(hi, lo, q.q, q.barrett_hi, q.barrett_lo);
+}
+
+__global__ __launch_bounds__(256) void add_plain_kernel(u64 *__restrict__ cts, const u64 *__restrict__ pts,
+                                                        size_t total, int logN, int sub, BfvConsts b, int lv,
+                                                        const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const LevelConsts &c = b.lv[lv];
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const u64 m = pts[idx];
+  if (m == 0) return;
+  const u64 fix = scale_fix(m, b, c);
+  for (int l = 0; l < c.limbs; ++l) {
+    const DevMod &q = mods[l];
+    const u64 s = scaled_plain(m, fix, c.delta_mod_q[l], q);
+    u64 *d = cts + (((k * 2) * c.limbs + l) << logN) + i;
+    *d = sub ? sub_mod(*d, s, q.q) : add_mod(*d, s, q.q);
+  }
+}
+
+__global__ __launch_bounds__(256) void plain_lift_kernel(const u64 *__restrict__ pts, u64 *__restrict__ out,
+                                                         size_t total, int logN, int limbs, u64 t, u64 thr,
+                                                         const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const u64 m = pts[idx];
+  for (int l = 0; l < limbs; ++l) out[((k * limbs + l) << logN) + i] = m >= thr ? m + (mods[l].q - t) : m;
+}
+
+// out[o1][o2] = sum_k ct[...] (.) pt[...], TM outputs along o1 per thread so that each ct
+// coefficient is loaded once per TM plaintext coefficients.  128-bit lazy accumulation,
+// reduced every 8 terms.
+template <int TM>
+__global__ __launch_bounds__(256) void dyadic_mac_kernel(const u64 *__restrict__ cts, const u64 *__restrict__ pts,
+                                                         u64 *__restrict__ out, int logN, int limbs, unsigned n_o1,
+                                                         unsigned n_o2, unsigned K, size_t ct_sk, size_t ct_s2,
+                                                         size_t pt_s1, size_t pt_sk, size_t pt_s2,
+                                                         const DevMod *__restrict__ mods) {
+  const unsigned blocks_per_limb = (1u << logN) / 256;
+  const int l = blockIdx.x / blocks_per_limb;
+  const size_t i = (size_t)(blockIdx.x % blocks_per_limb) * 256 + threadIdx.x;
+  const unsigned o2 = blockIdx.y, o1_base = blockIdx.z * TM;
+  const DevMod q = mods[l];
+  const size_t poly = size_t(1) << logN;
+  u64 lo[TM][2], hi[TM][2];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) lo[j][0] = lo[j][1] = hi[j][0] = hi[j][1] = 0;
+  for (unsigned k = 0; k < K; ++k) {
+    const size_t ct = k * ct_sk + o2 * ct_s2;
+    const u64 c0 = cts[((ct * 2 + 0) * limbs + l) * poly + i];
+    const u64 c1 = cts[((ct * 2 + 1) * limbs + l) * poly + i];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      if (o1_base + j < n_o1) {
+        const size_t pt = (o1_base + j) * pt_s1 + k * pt_sk + o2 * pt_s2;
+        const u64 w = pts[(pt * limbs + l) * poly + i];
+        u64 p = c0 * w;
+        lo[j][0] += p;
+        hi[j][0] += mulhi64(c0, w) + (lo[j][0] < p);
+        p = c1 * w;
+        lo[j][1] += p;
+        hi[j][1] += mulhi64(c1, w) + (lo[j][1] < p);
+      }
+    }
+    // Barrett's 64-bit quotient needs the sum below q*2^64: 8 products of < q^2 with q < 2^61
+    if ((k & 7) == 7) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          lo[j][c] = reduce128_wide(hi[j][c], lo[j][c], q);
+          hi[j][c] = 0;
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+    if (o1_base + j < n_o1) {
+      const size_t o = (size_t)(o1_base + j) * n_o2 + o2;
+      out[((o * 2 + 0) * limbs + l) * poly + i] = reduce128_wide(hi[j][0], lo[j][0], q);
+      out[((o * 2 + 1) * limbs + l) * poly + i] = reduce128_wide(hi[j][1], lo[j][1], q);
+    }
+}
+
+// c = a (+|-) b element-wise over [n_polys][limbs][N]; b may be signed noise broadcast over limbs
+__global__ __launch_bounds__(256) void poly_add_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, size_t total,
+                                                       int logN, int limbs, int sub, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const u64 q = mods[(idx >> logN) % limbs].q;
+  a[idx] = sub ? sub_mod(a[idx], b[idx], q) : add_mod(a[idx], b[idx], q);
+}
+
+// ct.c0 -= r : cts [n][2][limbs][N], r [n][limbs][N]
+__global__ __launch_bounds__(256) void sub_c0_kernel(u64 *__restrict__ cts, const u64 *__restrict__ r, size_t total,
+                                                     int logN, int limbs, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t i = idx & ((size_t(1) << logN) - 1), pl = idx >> logN;  // pl = k*limbs + l
+  const size_t k = pl / limbs, l = pl % limbs;
+  u64 *d = cts + (((k * 2) * limbs + l) << logN) + i;
+  *d = sub_mod(*d, r[idx], mods[l].q);
+}
+
+__global__ __launch_bounds__(256) void mod_switch_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                         size_t total, int logN, u64 inv_qlast,
+                                                         const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n*2][N]
+  if (idx >= total) return;
+  const size_t i = idx & ((size_t(1) << logN) - 1), p = idx >> logN;
+  const DevMod &q0 = mods[0];
+  const u64 q1 = mods[1].q, half = q1 >> 1;
+  u64 last = in[((p * 2 + 1) << logN) + i] + half;
+  last = csub(last, q1);
+  const u64 tmp = sub_mod(reduce64(last, q0), reduce64(half, q0), q0.q);
+  const u64 x = sub_mod(in[((p * 2) << logN) + i], tmp, q0.q);
+  out[idx] = mul_mod(x, inv_qlast, q0);
+}
+
+// signed small polynomial [n][N] -> RNS [n][limbs][N]
+__global__ __launch_bounds__(256) void signed_to_rns_kernel(const int64_t *__restrict__ v, u64 *__restrict__ out,
+                                                            size_t total, int logN, int limbs,
+                                                            const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const int64_t x = v[idx];
+  for (int l = 0; l < limbs; ++l) out[((k * limbs + l) << logN) + i] = signed_to_mod(x, mods[l].q);
+}
+
+// out[k][j][l] = u_ntt[k][l] (.) pk[j][l]
+__global__ __launch_bounds__(256) void mul_pk_kernel(const u64 *__restrict__ u_ntt, const u64 *__restrict__ pk,
+                                                     u64 *__restrict__ out, size_t total, int logN, int limbs,
+                                                     const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][limbs][N]
+  if (idx >= total) return;
+  const size_t i = idx & ((size_t(1) << logN) - 1), pl = idx >> logN;
+  const size_t k = pl / limbs, l = pl % limbs;
+  const DevMod &q = mods[l];
+  const u64 u = u_ntt[idx];
+  for (int j = 0; j < 2; ++j)
+    out[(((k * 2 + j) * limbs + l) << logN) + i] = mul_mod(u, pk[((j * limbs + l) << logN) + i], q);
+}
+
+// ct[k][j][l][i] += e_j[k][i]
+__global__ __launch_bounds__(256) void add_noise_kernel(u64 *__restrict__ cts, const int64_t *__restrict__ e0,
+                                                        const int64_t *__restrict__ e1, size_t total, int logN,
+                                                        int limbs, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  for (int j = 0; j < 2; ++j) {
+    const int64_t *e = j ? e1 : e0;
+    if (!e) continue;
+    const int64_t x = e[idx];
+    for (int l = 0; l < limbs; ++l) {
+      u64 *d = cts + (((k * 2 + j) * limbs + l) << logN) + i;
+      *d = add_mod(*d, signed_to_mod(x, mods[l].q), mods[l].q);
+    }
+  }
+}
+
+// tmp[k][l] (.)= key[l]   (key broadcast over k)
+__global__ __launch_bounds__(256) void mul_key_kernel(u64 *__restrict__ tmp, const u64 *__restrict__ key,
+                                                      size_t total, int logN, int limbs,
+                                                      const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t i = idx & ((size_t(1) << logN) - 1), l = (idx >> logN) % limbs;
+  tmp[idx] = mul_mod(tmp[idx], key[(l << logN) + i], mods[l]);
+}
+
+// gather polynomial `which` of every ciphertext: dst[k][l] = cts[k][which][l]
+__global__ __launch_bounds__(256) void gather_poly_kernel(const u64 *__restrict__ cts, u64 *__restrict__ dst,
+                                                          size_t total, int logN, int limbs, int which) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t i = idx & ((size_t(1) << logN) - 1), pl = idx >> logN;
+  const size_t k = pl / limbs, l = pl % limbs;
+  dst[idx] = cts[(((k * 2 + which) * limbs + l) << logN) + i];
+}
+
+// symmetric encryption tail: c0 = -(as + e) + scaled(m), c1 = a
+__global__ __launch_bounds__(256) void sym_finish_kernel(const u64 *__restrict__ as, const u64 *__restrict__ a,
+                                                         const int64_t *__restrict__ e, const u64 *__restrict__ pts,
+                                                         u64 *__restrict__ out, size_t total, int logN, BfvConsts b,
+                                                         int lv, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  if (idx >= total) return;
+  const LevelConsts &c = b.lv[lv];
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const int64_t x = e[idx];
+  const u64 m = pts ? pts[idx] : 0;
+  const u64 fix = m ? scale_fix(m, b, c) : 0;
+  for (int l = 0; l < c.limbs; ++l) {
+    const DevMod &q = mods[l];
+    const size_t src = ((k * c.limbs + l) << logN) + i;
+    u64 v = add_mod(as[src], signed_to_mod(x, q.q), q.q);
+    v = v ? q.q - v : 0;
+    if (m) v = add_mod(v, scaled_plain(m, fix, c.delta_mod_q[l], q), q.q);
+    out[(((k * 2) * c.limbs + l) << logN) + i] = v;
+    out[(((k * 2 + 1) * c.limbs + l) << logN) + i] = a[src];
+  }
+}
+
+// pk = (-(a s + e), a), all NTT form; e_ntt [L][N]
+__global__ __launch_bounds__(256) void pk_kernel(const u64 *__restrict__ sk, const u64 *__restrict__ a,
+                                                 const u64 *__restrict__ e_ntt, u64 *__restrict__ pk, size_t total,
+                                                 int logN, int limbs, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [L][N]
+  if (idx >= total) return;
+  const size_t l = idx >> logN;
+  const DevMod &q = mods[l];
+  const u64 v = add_mod(mul_mod(a[idx], sk[idx], q), e_ntt[idx], q.q);
+  pk[idx] = v ? q.q - v : 0;
+  pk[idx + ((size_t)limbs << logN)] = a[idx];
+}
+
+// RNSTool::decrypt_scale_and_round on x[l] (one coefficient, all limbs of the level)
+__device__ __forceinline__ u64 behz_round(const u64 *x, const BfvConsts &b, const LevelConsts &c,
+                                          const DevMod *__restrict__ mods) {
+  u64 t_lo = 0, t_hi = 0, g_lo = 0, g_hi = 0;
+  for (int l = 0; l < c.limbs; ++l) {
+    const DevMod &q = mods[l];
+    u64 v = mul_mod(x[l], c.prod_t_gamma_mod_q[l], q);
+    v = mul_mod(v, c.inv_punct_mod_q[l], q);
+    u64 p = v * c.punct_mod_t[l];
+    t_lo += p;
+    t_hi += mulhi64(v, c.punct_mod_t[l]) + (t_lo < p);
+    p = v * c.punct_mod_gamma[l];
+    g_lo += p;
+    g_hi += mulhi64(v, c.punct_mod_gamma[l]) + (g_lo < p);
+  }
+  const u64 vt = mulmod_c(reduce128(t_hi, t_lo, b.t), c.neg_inv_q_mod_t, b.t);
+  const u64 vg = mulmod_c(reduce128(g_hi, g_lo, b.gamma), c.neg_inv_q_mod_gamma, b.gamma);
+  const u64 t = b.t.q, g = b.gamma.q;
+  u64 r;
+  if (vg > (g >> 1)) {
+    r = add_mod(vt, reduce128(0, g - vg, b.t), t);
+  } else {
+    r = sub_mod(vt, reduce128(0, vg, b.t), t);
+  }
+  return r ? mulmod_c(r, b.inv_gamma_mod_t, b.t) : 0;
+}
+
+// decrypt tail: (tmp[k][l] + c0[k][l]) -> scale and round -> pts[k]
+__global__ __launch_bounds__(256) void decrypt_finish_kernel(const u64 *__restrict__ tmp, const u64 *__restrict__ cts,
+                                                             u64 *__restrict__ pts, size_t total, int logN,
+                                                             BfvConsts b, int lv, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  if (idx >= total) return;
+  const LevelConsts &c = b.lv[lv];
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  u64 x[2];
+  for (int l = 0; l < c.limbs; ++l)
+    x[l] = add_mod(tmp[((k * c.limbs + l) << logN) + i], cts[(((k * 2) * c.limbs + l) << logN) + i], mods[l].q);
+  pts[idx] = behz_round(x, b, c, mods);
+}
+
+__global__ __launch_bounds__(256) void scale_round_kernel(const u64 *__restrict__ polys, const u32 *__restrict__ targets,
+                                                          u64 *__restrict__ out, size_t n, size_t n_targets,
+                                                          int logN, BfvConsts b, int lv,
+                                                          const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][n_targets]
+  if (idx >= n * n_targets) return;
+  const LevelConsts &c = b.lv[lv];
+  const size_t k = idx / n_targets, j = idx % n_targets;
+  const size_t i = targets ? targets[j] : j;
+  u64 x[2];
+  for (int l = 0; l < c.limbs; ++l) x[l] = polys[((k * c.limbs + l) << logN) + i];
+  out[idx] = behz_round(x, b, c, mods);
+}
+
+__global__ __launch_bounds__(256) void truncate_kernel(u64 *__restrict__ cts, size_t total, int logN, u64 mask0,
+                                                       u64 mask1, const uint8_t *__restrict__ keep,
+                                                       size_t keep_period) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const bool kept = !keep || keep[((k % keep_period) << logN) + i];
+  u64 *c0 = cts + ((k * 2) << logN) + i, *c1 = c0 + (size_t(1) << logN);
+  *c0 = kept ? (*c0 & mask0) : 0;  // remove_unused_coeffs walks ct.data(0) only: c1 keeps every coefficient
+  *c1 &= mask1;
+}
+
+__global__ __launch_bounds__(256) void slot_scatter_kernel(const u64 *__restrict__ vals, u64 *__restrict__ pts,
+                                                           size_t total, int logN, const u32 *__restrict__ map,
+                                                           ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  pts[(k << logN) + map[i]] = reduce128(0, vals[idx], t);
+}
+__global__ __launch_bounds__(256) void slot_gather_kernel(const u64 *__restrict__ tmp, u64 *__restrict__ vals,
+                                                          size_t total, int logN, const u32 *__restrict__ map) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  vals[idx] = tmp[(k << logN) + map[i]];
+}
+
+static inline unsigned blocks_for(size_t total) { return (unsigned)((total + 255) / 256); }
+
+static int check_bfv(const mmh_ctx *ctx, int lv) {
+  MMH_REQUIRE(ctx, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
+  MMH_REQUIRE(lv == 0 || lv == 1, MMH_ERR_INVALID_ARG);
+  return MMH_OK;
+}
+static inline int limbs_of(const mmh_ctx *ctx, int lv) { return lv == 0 ? (int)ctx->L : 1; }
+}  // namespace mmh
+
+using namespace mmh;
+#define CHECK_RC(x)        \
+  do {                     \
+    int rc_ = (x);         \
+    if (rc_) return rc_;   \
+  } while (0)
+#define LAUNCH(kern, total, s, ...)                                                  \
+  do {                                                                               \
+    if ((total) > 0) {                                                               \
+      hipLaunchKernelGGL(kern, dim3(blocks_for(total)), dim3(256), 0, s, __VA_ARGS__); \
+      MMH_HIP(hipGetLastError());                                                    \
+    }                                                                                \
+  } while (0)
+
+extern "C" int mmh_add_plain(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, const uint64_t *d_pts,
+                             size_t n, int sub, uint64_t *d_out, void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts && d_pts && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = ctx->N;
+  const int limbs = limbs_of(ctx, lv);
+  if (d_out != d_cts)
+    MMH_HIP(hipMemcpyAsync(d_out, d_cts, n * 2 * limbs * N * 8, hipMemcpyDeviceToDevice, s));
+  LAUNCH(add_plain_kernel, n * N, s, d_out, d_pts, n * N, ctx->logN, sub, ctx->bfv, lv, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_plain_lift_ntt(const mmh_ctx *ctx, int lv, const uint64_t *d_pts, size_t n,
+                                  uint64_t *d_out, void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_pts && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const int limbs = limbs_of(ctx, lv);
+  LAUNCH(plain_lift_kernel, n * ctx->N, s, d_pts, d_out, n * ctx->N, ctx->logN, limbs, ctx->t, ctx->bfv.thr,
+         ctx->d_mods);
+  return ntt_dispatch(ctx, false, d_out, n, limbs, 0, s);
+}
+
+extern "C" int mmh_dyadic_mac(const mmh_ctx *ctx, int lv, const uint64_t *d_cts_ntt, size_t n_cts,
+                              const uint64_t *d_pts_ntt, size_t n_pts, size_t n_o1, size_t n_o2, size_t K,
+                              size_t ct_sk, size_t ct_s2, size_t pt_s1, size_t pt_sk, size_t pt_s2,
+                              uint64_t *d_out_ntt, void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n_o1 == 0 || n_o2 == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts_ntt && d_pts_ntt && d_out_ntt, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(K >= 1, MMH_ERR_INVALID_ARG);
+  // every index the kernel forms must lie inside the operand arrays
+  MMH_REQUIRE((K - 1) * ct_sk + (n_o2 - 1) * ct_s2 < n_cts, MMH_ERR_OUT_BOUND);
+  MMH_REQUIRE((n_o1 - 1) * pt_s1 + (K - 1) * pt_sk + (n_o2 - 1) * pt_s2 < n_pts, MMH_ERR_OUT_BOUND);
+  MMH_REQUIRE(n_o2 <= 65535 && (n_o1 + 3) / 4 <= 65535, MMH_ERR_OUT_BOUND);
+  const int limbs = limbs_of(ctx, lv);
+  dim3 grid((unsigned)(ctx->N / 256 * limbs), (unsigned)n_o2, (unsigned)((n_o1 + 3) / 4));
+  hipLaunchKernelGGL(dyadic_mac_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, d_cts_ntt, d_pts_ntt,
+                     d_out_ntt, ctx->logN, limbs, (unsigned)n_o1, (unsigned)n_o2, (unsigned)K, ct_sk, ct_s2,
+                     pt_s1, pt_sk, pt_s2, ctx->d_mods);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_mul_plain_acc(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, size_t n_cts,
+                                 const uint64_t *d_pts, size_t n_pts, size_t n_o1, size_t n_o2, size_t K,
+                                 size_t ct_sk, size_t ct_s2, size_t pt_s1, size_t pt_sk, size_t pt_s2,
+                                 uint64_t *d_out, void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n_o1 == 0 || n_o2 == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts && d_pts && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const int limbs = limbs_of(ctx, lv);
+  const size_t poly = ctx->N * 8;
+  StreamBuf ct_ntt(s), pt_ntt(s);
+  MMH_HIP(ct_ntt.alloc(n_cts * 2 * limbs * poly));
+  MMH_HIP(pt_ntt.alloc(n_pts * limbs * poly));
+  MMH_HIP(hipMemcpyAsync(ct_ntt.p, d_cts, n_cts * 2 * limbs * poly, hipMemcpyDeviceToDevice, s));
+  CHECK_RC(ntt_dispatch(ctx, false, ct_ntt.as<u64>(), n_cts * 2, limbs, 0, s));
+  CHECK_RC(mmh_plain_lift_ntt(ctx, lv, d_pts, n_pts, pt_ntt.as<u64>(), stream));
+  CHECK_RC(mmh_dyadic_mac(ctx, lv, ct_ntt.as<u64>(), n_cts, pt_ntt.as<u64>(), n_pts, n_o1, n_o2, K, ct_sk,
+                          ct_s2, pt_s1, pt_sk, pt_s2, d_out, stream));
+  return ntt_dispatch(ctx, true, d_out, n_o1 * n_o2 * 2, limbs, 0, s);
+}
+
+extern "C" int mmh_ct_add(const mmh_ctx *ctx, int lv, uint64_t *d_a, const uint64_t *d_b, size_t n,
+                          void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_a && d_b, MMH_ERR_NULL_POINTER);
+  const int limbs = limbs_of(ctx, lv);
+  const size_t total = n * 2 * limbs * ctx->N;
+  LAUNCH(poly_add_kernel, total, (hipStream_t)stream, d_a, d_b, total, ctx->logN, limbs, 0, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_mod_switch_to_last(const mmh_ctx *ctx, const uint64_t *d_in, size_t n, uint64_t *d_out,
+                                      void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->L == 1) {
+    MMH_HIP(hipMemcpyAsync(d_out, d_in, n * 2 * ctx->N * 8, hipMemcpyDeviceToDevice, s));
+    return MMH_OK;
+  }
+  const size_t total = n * 2 * ctx->N;
+  LAUNCH(mod_switch_kernel, total, s, d_in, d_out, total, ctx->logN, ctx->bfv.inv_qlast_mod_q0, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_encrypt_zero_asym(const mmh_ctx *ctx, int lv, const uint64_t *d_pk_ntt, const int64_t *d_u,
+                                     const int64_t *d_e0, const int64_t *d_e1, size_t n, uint64_t *d_out,
+                                     void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_pk_ntt && d_u && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const int limbs = limbs_of(ctx, lv);
+  const size_t N = ctx->N;
+  StreamBuf u(s);
+  MMH_HIP(u.alloc(n * limbs * N * 8));
+  LAUNCH(signed_to_rns_kernel, n * N, s, d_u, u.as<u64>(), n * N, ctx->logN, limbs, ctx->d_mods);
+  CHECK_RC(ntt_dispatch(ctx, false, u.as<u64>(), n, limbs, 0, s));
+  LAUNCH(mul_pk_kernel, n * limbs * N, s, u.as<u64>(), d_pk_ntt, d_out, n * limbs * N, ctx->logN, limbs,
+         ctx->d_mods);
+  CHECK_RC(ntt_dispatch(ctx, true, d_out, n * 2, limbs, 0, s));
+  if (d_e0 || d_e1) LAUNCH(add_noise_kernel, n * N, s, d_out, d_e0, d_e1, n * N, ctx->logN, limbs, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_encrypt_symmetric(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt, const uint64_t *d_a,
+                                     const int64_t *d_e, const uint64_t *d_pts, size_t n, uint64_t *d_out,
+                                     void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_sk_ntt && d_a && d_e && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const int limbs = limbs_of(ctx, lv);
+  const size_t N = ctx->N, total = n * limbs * N;
+  StreamBuf as(s);
+  MMH_HIP(as.alloc(total * 8));
+  MMH_HIP(hipMemcpyAsync(as.p, d_a, total * 8, hipMemcpyDeviceToDevice, s));
+  CHECK_RC(ntt_dispatch(ctx, false, as.as<u64>(), n, limbs, 0, s));
+  LAUNCH(mul_key_kernel, total, s, as.as<u64>(), d_sk_ntt, total, ctx->logN, limbs, ctx->d_mods);
+  CHECK_RC(ntt_dispatch(ctx, true, as.as<u64>(), n, limbs, 0, s));
+  LAUNCH(sym_finish_kernel, n * N, s, as.as<u64>(), d_a, d_e, d_pts, d_out, n * N, ctx->logN, ctx->bfv, lv,
+         ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_make_public_key(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_a_ntt,
+                                   const int64_t *d_e, uint64_t *d_pk_ntt, void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  MMH_REQUIRE(d_sk_ntt && d_a_ntt && d_e && d_pk_ntt, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const int limbs = (int)ctx->L;
+  const size_t N = ctx->N;
+  StreamBuf e(s);
+  MMH_HIP(e.alloc(limbs * N * 8));
+  LAUNCH(signed_to_rns_kernel, N, s, d_e, e.as<u64>(), N, ctx->logN, limbs, ctx->d_mods);
+  CHECK_RC(ntt_dispatch(ctx, false, e.as<u64>(), 1, limbs, 0, s));
+  LAUNCH(pk_kernel, limbs * N, s, d_sk_ntt, d_a_ntt, e.as<u64>(), d_pk_ntt, limbs * N, ctx->logN, limbs,
+         ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_decrypt(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
+                           size_t n, uint64_t *d_pts, void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_sk_ntt && d_cts && d_pts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  const int limbs = limbs_of(ctx, lv);
+  const size_t N = ctx->N, total = n * limbs * N;
+  StreamBuf tmp(s);
+  MMH_HIP(tmp.alloc(total * 8));
+  LAUNCH(gather_poly_kernel, total, s, d_cts, tmp.as<u64>(), total, ctx->logN, limbs, 1);
+  CHECK_RC(ntt_dispatch(ctx, false, tmp.as<u64>(), n, limbs, 0, s));
+  LAUNCH(mul_key_kernel, total, s, tmp.as<u64>(), d_sk_ntt, total, ctx->logN, limbs, ctx->d_mods);
+  CHECK_RC(ntt_dispatch(ctx, true, tmp.as<u64>(), n, limbs, 0, s));
+  LAUNCH(decrypt_finish_kernel, n * N, s, tmp.as<u64>(), d_cts, d_pts, n * N, ctx->logN, ctx->bfv, lv,
+         ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_scale_and_round(const mmh_ctx *ctx, int lv, const uint64_t *d_polys, size_t n,
+                                   const uint32_t *d_targets, size_t n_targets, uint64_t *d_out,
+                                   void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (!d_targets) n_targets = ctx->N;
+  if (n == 0 || n_targets == 0) return MMH_OK;
+  MMH_REQUIRE(d_polys && d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(n_targets <= ctx->N, MMH_ERR_OUT_BOUND);
+  LAUNCH(scale_round_kernel, n * n_targets, (hipStream_t)stream, d_polys, d_targets, d_out, n, n_targets,
+         ctx->logN, ctx->bfv, lv, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_sub_rns_poly(const mmh_ctx *ctx, int lv, uint64_t *d_cts, const uint64_t *d_r, size_t n,
+                                void *stream) {
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts && d_r, MMH_ERR_NULL_POINTER);
+  const int limbs = limbs_of(ctx, lv);
+  const size_t total = n * limbs * ctx->N;
+  LAUNCH(sub_c0_kernel, total, (hipStream_t)stream, d_cts, d_r, total, ctx->logN, limbs, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_truncate_masks(const mmh_ctx *ctx, uint64_t *mask0, uint64_t *mask1) {
+  CHECK_RC(check_bfv(ctx, 1));
+  MMH_REQUIRE(mask0 && mask1, MMH_ERR_NULL_POINTER);
+  *mask0 = ctx->bfv.mask0;
+  *mask1 = ctx->bfv.mask1;
+  return MMH_OK;
+}
+
+extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t n, const uint8_t *d_keep,
+                                     size_t keep_period, void *stream) {
+  CHECK_RC(check_bfv(ctx, 1));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!d_keep || keep_period >= 1, MMH_ERR_INVALID_ARG);
+  LAUNCH(truncate_kernel, n * ctx->N, (hipStream_t)stream, d_cts, n * ctx->N, ctx->logN, ctx->bfv.mask0,
+         ctx->bfv.mask1, d_keep, keep_period ? keep_period : 1);
+  return MMH_OK;
+}
+
+extern "C" int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts,
+                                void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_vals && d_pts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  LAUNCH(slot_scatter_kernel, n * ctx->N, s, d_vals, d_pts, n * ctx->N, ctx->logN, ctx->d_slot_map, ctx->bfv.t);
+  return ntt_dispatch(ctx, true, d_pts, n, 1, (int)ctx->L, s);
+}
+
+extern "C" int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals,
+                                void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_vals && d_pts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  StreamBuf tmp(s);
+  MMH_HIP(tmp.alloc(n * ctx->N * 8));
+  MMH_HIP(hipMemcpyAsync(tmp.p, d_pts, n * ctx->N * 8, hipMemcpyDeviceToDevice, s));
+  CHECK_RC(ntt_dispatch(ctx, false, tmp.as<u64>(), n, 1, (int)ctx->L, s));
+  LAUNCH(slot_gather_kernel, n * ctx->N, s, tmp.as<u64>(), d_vals, n * ctx->N, ctx->logN, ctx->d_slot_map);
+  return MMH_OK;
+}

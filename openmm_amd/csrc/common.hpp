@@ -28,6 +28,34 @@ struct DevMod {
   u64 tw_offset;               // fwd = tables + tw_offset, inv = fwd + N (one allocation per context)
 };
 
+// A modulus without NTT tables (plain modulus t, BEHZ gamma): Barrett only.
+struct ModC {
+  u64 q;
+  u64 barrett_hi, barrett_lo;
+};
+
+// BFV / BEHZ constants of one level (SEAL ContextData + RNSTool), passed to kernels by value.
+struct LevelConsts {
+  int limbs;
+  u64 delta_mod_q[2];         // floor(Q/t) mod q_l
+  u64 q_mod_t;                // Q mod t
+  u64 prod_t_gamma_mod_q[2];  // t*gamma mod q_l
+  u64 inv_punct_mod_q[2];     // (Q/q_l)^-1 mod q_l
+  u64 punct_mod_t[2];         // Q/q_l mod t
+  u64 punct_mod_gamma[2];     // Q/q_l mod gamma
+  u64 neg_inv_q_mod_t, neg_inv_q_mod_gamma;
+};
+struct BfvConsts {
+  ModC t, gamma;
+  u64 thr;              // (t+1)/2: plain_upper_half_threshold
+  int t_log2;           // log2(t) when t is a power of two, else -1
+  u64 t_inv64;          // t^-1 mod 2^64 for odd t (exact division)
+  u64 inv_gamma_mod_t;
+  u64 inv_qlast_mod_q0; // q1^-1 mod q0 (mod-switch to the last level)
+  u64 mask0, mask1;     // truncate_for_decryption
+  LevelConsts lv[2];
+};
+
 void set_error(const std::string &msg);
 
 #define MMH_FAIL(code, msg)                                                    \
@@ -146,5 +174,7 @@ struct mmh_ctx {
   mmh::DevMod *d_mods = nullptr;
   ulonglong2 *d_tables = nullptr;  // all twiddle tables, [(fwd,inv) per modulus][N]
   mmh::DevMod h_mods[mmh::kMaxLimbs + 1];
+  mmh::BfvConsts bfv;              // valid when t >= 2
+  uint32_t *d_slot_map = nullptr;  // BatchEncoder index map (batching only)
   std::vector<void *> allocs;
 };

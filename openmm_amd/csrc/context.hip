@@ -36,6 +36,76 @@ static void build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out, std::vector<ulo
   out->ninv_sh = shoup(out->ninv, m);
   out->tw_offset = base;
 }
+static ModC make_modc(u64 m) {
+  const u128 ratio = m & (m - 1) ? ~(u128)0 / m : (~(u128)0 / m) + 1;
+  return ModC{m, (u64)(ratio >> 64), (u64)ratio};
+}
+
+// SEAL ContextData / RNSTool constants for both levels; Q < 2^128 because L <= 2.
+static int build_bfv(mmh_ctx *ctx) {
+  BfvConsts &b = ctx->bfv;
+  const u64 t = ctx->t;
+  const size_t N = ctx->N;
+  b.t = make_modc(t);
+  b.gamma = make_modc(ctx->gamma);
+  b.thr = (t + 1) >> 1;
+  b.t_log2 = ctx->t_pow2 ? bit_count(t) - 1 : -1;
+  b.t_inv64 = 0;
+  if (t & 1) {  // Newton iteration for t^-1 mod 2^64
+    u64 x = t;
+    for (int i = 0; i < 6; ++i) x *= 2 - t * x;
+    b.t_inv64 = x;
+  }
+  MMH_REQUIRE(ctx->t_pow2 || (t & 1), MMH_ERR_CONFIG);  // t = 2^k or odd, as in the reference
+  b.inv_gamma_mod_t = inv_mod(ctx->gamma % t, t);
+  MMH_REQUIRE(b.inv_gamma_mod_t != 0 || t == 1, MMH_ERR_CONFIG);
+  b.inv_qlast_mod_q0 = ctx->L == 2 ? inv_mod(ctx->q[1] % ctx->q[0], ctx->q[0]) : 0;
+  // truncate_for_decryption widths (hom_conv2d_ss.cc:418-436); (int)log2(12*N*sqrt(1/18)) = logN+1
+  const int n_delta_bits = bit_count(ctx->q[0]) - bit_count(t);
+  auto bits_mask = [](int z) {
+    z = z < 0 ? 0 : (z > 63 ? 63 : z);
+    return (~u64(0) >> z) << z;
+  };
+  b.mask0 = bits_mask(n_delta_bits - 1 - (ctx->t_pow2 ? 0 : 1));
+  b.mask1 = bits_mask(n_delta_bits - (ctx->logN + 1));
+  for (int lv = 0; lv < 2; ++lv) {
+    LevelConsts &c = b.lv[lv];
+    c.limbs = lv == 0 ? (int)ctx->L : 1;
+    u128 Q = 1;
+    for (int l = 0; l < c.limbs; ++l) Q *= ctx->q[l];
+    c.q_mod_t = (u64)(Q % t);
+    const u128 delta = Q / t;
+    for (int l = 0; l < c.limbs; ++l) {
+      const u64 ql = ctx->q[l];
+      const u128 punct = Q / ql;
+      c.delta_mod_q[l] = (u64)(delta % ql);
+      c.prod_t_gamma_mod_q[l] = mul_mod(t % ql, ctx->gamma % ql, ql);
+      c.inv_punct_mod_q[l] = inv_mod((u64)(punct % ql), ql);
+      c.punct_mod_t[l] = (u64)(punct % t);
+      c.punct_mod_gamma[l] = (u64)(punct % ctx->gamma);
+    }
+    const u64 it = inv_mod((u64)(Q % t), t), ig = inv_mod((u64)(Q % ctx->gamma), ctx->gamma);
+    MMH_REQUIRE(it != 0 || t == 1, MMH_ERR_CONFIG);  // gcd(Q, t) = 1
+    c.neg_inv_q_mod_t = (t - it) % t;
+    c.neg_inv_q_mod_gamma = ctx->gamma - ig;
+  }
+  if (ctx->batching) {
+    // BatchEncoder::populate_matrix_reps_index_map: powers of the generator 3 mod 2N
+    std::vector<uint32_t> map(N);
+    const size_t m = 2 * N, row = N / 2;
+    u64 pos = 1;
+    for (size_t i = 0; i < row; ++i) {
+      map[i] = bit_reverse((uint32_t)((pos - 1) >> 1), ctx->logN);
+      map[row + i] = bit_reverse((uint32_t)((m - pos - 1) >> 1), ctx->logN);
+      pos = (pos * 3) & (m - 1);
+    }
+    void *d = nullptr;
+    int rc = upload(ctx, map.data(), N * sizeof(uint32_t), &d);
+    if (rc) return rc;
+    ctx->d_slot_map = (uint32_t *)d;
+  }
+  return MMH_OK;
+}
 }  // namespace mmh
 
 using namespace mmh;
@@ -93,8 +163,9 @@ extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t
     }
   }
   if (!rc && t > 1) {
-    auto g = primes_below(2 * N, 61, 2);
+    auto g = primes_below(2 * N, 61, 2);  // RNSTool::initialize: {m_sk, gamma, ...}
     ctx->gamma = g.size() == 2 ? g[1] : 0;
+    rc = build_bfv(ctx);
   }
   if (!rc) {
     void *d = nullptr;

@@ -41,6 +41,22 @@ SIGNATURES = {
     "mmh_ntt_inverse": [_vp, _vp, _sz, _sz, _vp],
     "mmh_ntt_forward_t": [_vp, _vp, _sz, _vp],
     "mmh_ntt_inverse_t": [_vp, _vp, _sz, _vp],
+    "mmh_add_plain": [_vp, _int, _vp, _vp, _sz, _int, _vp, _vp],
+    "mmh_plain_lift_ntt": [_vp, _int, _vp, _sz, _vp, _vp],
+    "mmh_dyadic_mac": [_vp, _int, _vp, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp],
+    "mmh_mul_plain_acc": [_vp, _int, _vp, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp],
+    "mmh_ct_add": [_vp, _int, _vp, _vp, _sz, _vp],
+    "mmh_mod_switch_to_last": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_encrypt_zero_asym": [_vp, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
+    "mmh_encrypt_symmetric": [_vp, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
+    "mmh_make_public_key": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_decrypt": [_vp, _int, _vp, _vp, _sz, _vp, _vp],
+    "mmh_scale_and_round": [_vp, _int, _vp, _sz, _vp, _sz, _vp, _vp],
+    "mmh_sub_rns_poly": [_vp, _int, _vp, _vp, _sz, _vp],
+    "mmh_truncate_masks": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
+    "mmh_truncate_and_zero": [_vp, _vp, _sz, _vp, _sz, _vp],
+    "mmh_batch_encode": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_batch_decode": [_vp, _vp, _sz, _vp, _vp],
 }
 
 
@@ -75,7 +91,9 @@ def _stream_ptr():
 
 
 def dptr(t):
-    """Device pointer of a contiguous torch CUDA tensor (any 8-byte integer dtype)."""
+    """Device pointer of a contiguous torch CUDA tensor (None -> NULL)."""
+    if t is None:
+        return _vp(0)
     assert t.is_cuda and t.is_contiguous()
     return _vp(t.data_ptr())
 
@@ -148,3 +166,96 @@ class Context:
         check(self.lib.mmh_ntt_inverse_t(self.handle, dptr(polys), polys.numel() // self.N,
                                          _stream_ptr()))
         return polys
+
+    # ------------------------------------------------------------------ BFV batches
+    def limbs(self, lv):
+        return self.L if lv == 0 else 1
+
+    def _empty(self, *shape):
+        import torch
+        return torch.empty(shape, dtype=torch.int64, device=f"cuda:{self.device}")
+
+    def add_plain(self, cts, pts, lv=0, sub=False):
+        """seal::Evaluator::add_plain / sub_plain on [n,2,limbs,N] and [n,N]; returns new cts"""
+        out = self._empty(*cts.shape)
+        check(self.lib.mmh_add_plain(self.handle, lv, dptr(cts), dptr(pts), cts.shape[0], int(sub),
+                                     dptr(out), _stream_ptr()))
+        return out
+
+    def plain_lift_ntt(self, pts, lv=0):
+        out = self._empty(pts.shape[0], self.limbs(lv), self.N)
+        check(self.lib.mmh_plain_lift_ntt(self.handle, lv, dptr(pts), pts.shape[0], dptr(out), _stream_ptr()))
+        return out
+
+    def mul_plain_acc(self, cts, pts, n_o1, n_o2, K, ct_sk, ct_s2, pt_s1, pt_sk, pt_s2, lv=0):
+        out = self._empty(n_o1 * n_o2, 2, self.limbs(lv), self.N)
+        check(self.lib.mmh_mul_plain_acc(self.handle, lv, dptr(cts), cts.shape[0], dptr(pts), pts.shape[0],
+                                         n_o1, n_o2, K, ct_sk, ct_s2, pt_s1, pt_sk, pt_s2, dptr(out),
+                                         _stream_ptr()))
+        return out
+
+    def ct_add(self, a, b, lv=0):
+        check(self.lib.mmh_ct_add(self.handle, lv, dptr(a), dptr(b), a.shape[0], _stream_ptr()))
+        return a
+
+    def mod_switch_to_last(self, cts):
+        out = self._empty(cts.shape[0], 2, 1, self.N)
+        check(self.lib.mmh_mod_switch_to_last(self.handle, dptr(cts), cts.shape[0], dptr(out), _stream_ptr()))
+        return out
+
+    def encrypt_zero_asym(self, pk_ntt, u, e0, e1, lv=0):
+        out = self._empty(u.shape[0], 2, self.limbs(lv), self.N)
+        check(self.lib.mmh_encrypt_zero_asym(self.handle, lv, dptr(pk_ntt), dptr(u), dptr(e0), dptr(e1),
+                                             u.shape[0], dptr(out), _stream_ptr()))
+        return out
+
+    def encrypt_symmetric(self, sk_ntt, a, e, pts, lv=0):
+        out = self._empty(a.shape[0], 2, self.limbs(lv), self.N)
+        check(self.lib.mmh_encrypt_symmetric(self.handle, lv, dptr(sk_ntt), dptr(a), dptr(e), dptr(pts),
+                                             a.shape[0], dptr(out), _stream_ptr()))
+        return out
+
+    def make_public_key(self, sk_ntt, a_ntt, e):
+        out = self._empty(2, self.L, self.N)
+        check(self.lib.mmh_make_public_key(self.handle, dptr(sk_ntt), dptr(a_ntt), dptr(e), dptr(out),
+                                           _stream_ptr()))
+        return out
+
+    def decrypt(self, sk_ntt, cts, lv=0):
+        out = self._empty(cts.shape[0], self.N)
+        check(self.lib.mmh_decrypt(self.handle, lv, dptr(sk_ntt), dptr(cts), cts.shape[0], dptr(out),
+                                   _stream_ptr()))
+        return out
+
+    def scale_and_round(self, polys, targets=None, lv=0):
+        nt = self.N if targets is None else targets.numel()
+        out = self._empty(polys.shape[0], nt)
+        check(self.lib.mmh_scale_and_round(self.handle, lv, dptr(polys), polys.shape[0], dptr(targets), nt,
+                                           dptr(out), _stream_ptr()))
+        return out
+
+    def sub_rns_poly(self, cts, r, lv=0):
+        check(self.lib.mmh_sub_rns_poly(self.handle, lv, dptr(cts), dptr(r), cts.shape[0], _stream_ptr()))
+        return cts
+
+    def truncate_masks(self):
+        m0, m1 = _u64(), _u64()
+        check(self.lib.mmh_truncate_masks(self.handle, C.byref(m0), C.byref(m1)))
+        return m0.value, m1.value
+
+    def truncate_and_zero(self, cts, keep=None, keep_period=1):
+        check(self.lib.mmh_truncate_and_zero(self.handle, dptr(cts), cts.shape[0], dptr(keep), keep_period,
+                                             _stream_ptr()))
+        return cts
+
+    def batch_encode(self, vals):
+        out = self._empty(*vals.shape)
+        check(self.lib.mmh_batch_encode(self.handle, dptr(vals), vals.numel() // self.N, dptr(out),
+                                        _stream_ptr()))
+        return out
+
+    def batch_decode(self, pts):
+        out = self._empty(*pts.shape)
+        check(self.lib.mmh_batch_decode(self.handle, dptr(pts), pts.numel() // self.N, dptr(out),
+                                        _stream_ptr()))
+        return out
