@@ -174,6 +174,42 @@ int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t n, const u
 int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts, void *stream);
 int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals, void *stream);
 
+/* =====================================================================================
+ * Modulus conversion: local share arithmetic of SCI's Truncation class
+ * (SCI/src/BuildingBlocks/truncation.h:29-210), split around its single COT call.
+ * party: 1 = ALICE (the COT sender, truncation.cpp:549,607,665,351,412), 2 = BOB.
+ *   *_pre : d_tmp = input (+ "big number" for ALICE), d_msb = choice / wrap bit per element,
+ *           d_corr = sender correlation (ALICE only; may be NULL for BOB).
+ *   host  : ALICE send_cot[_prime](y, corr), BOB recv_cot[_prime](y, msb)  -- stays on host.
+ *   *_post: consumes y exactly as the reference does after the COT returns.
+ * No context is needed; work is enqueued on the current device.  in/out never alias-modified.
+ * ===================================================================================== */
+/* Truncation::ring_to_field (truncation.cpp:518-581); outputs are congruent mod p, not
+ * canonical, exactly like the reference's secure_sub on l-bit inputs (:538-541). */
+int mmh_r2f_pre(int party, const uint64_t *d_in, size_t n, int bw, uint64_t p, uint64_t *d_tmp,
+                uint8_t *d_msb, uint64_t *d_corr, void *stream);
+int mmh_r2f_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
+                 int bw, uint64_t p, uint64_t *d_out, void *stream);
+/* Truncation::field_to_ring (:583-637) and field_to_ring_with_truncate (:639-695); the pre
+ * step is shared, `shift` only enters the correlation p >> shift (0 for the plain variant) */
+int mmh_f2r_pre(int party, const uint64_t *d_in, size_t n, uint64_t p, int shift, uint64_t *d_tmp,
+                uint8_t *d_msb, uint64_t *d_corr, void *stream);
+int mmh_f2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
+                 uint64_t p, int bw, uint64_t *d_out, void *stream);
+int mmh_f2r_trunc_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
+                       uint64_t p, int bw, int shift, uint64_t *d_out, void *stream);
+/* Truncation::ring_to_ring (:319-381) and ring_to_ring128 (:383-442; d_out holds (lo,hi) pairs) */
+int mmh_r2r_pre(int party, const uint64_t *d_in, size_t n, int bw_a, uint64_t *d_tmp, uint8_t *d_msb,
+                uint64_t *d_corr, void *stream);
+int mmh_r2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
+                 int bw_a, int bw_b, uint64_t *d_out, void *stream);
+int mmh_r2r128_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
+                    int bw_a, int bw_b, uint64_t *d_out, void *stream);
+/* out[i] = (out[i] + moduloMult(x[i], y[i], p)) % p : the local cross term that closes
+ * CheetahLinear::BOLE (cheetah-api.cpp:648-649; sci::moduloMult utils.hpp:353-363) */
+int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n, uint64_t p,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

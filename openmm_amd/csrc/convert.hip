@@ -1,0 +1,213 @@
+// Modulus conversion between Z_{2^l} and Z_p: the LOCAL share arithmetic around the single
+// COT call of SCI's Truncation::{ring_to_field, field_to_ring, field_to_ring_with_truncate,
+// ring_to_ring, ring_to_ring128} (SCI/src/BuildingBlocks/truncation.cpp:319-695) and the BOLE
+// cross term (SCI/src/cheetah/cheetah-api.cpp:648-649).  Pure streaming kernels (HBM-bound,
+// ~25 B per element); the COT itself stays on the host.  party: 1 = ALICE (COT sender), 2 = BOB.
+#include "common.hpp"
+
+namespace mmh {
+constexpr int kAlice = 1;
+
+__device__ __forceinline__ u64 bw_mask(int bw) { return bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1; }
+// truncation.cpp:533-541.  x may exceed p (it is an l-bit ring value): keep the reference's
+// non-canonical results bit for bit.
+__device__ __forceinline__ u64 secure_add(u64 x, u64 y, u64 p) { return x >= (p - y) ? x - (p - y) : x + y; }
+__device__ __forceinline__ u64 secure_sub(u64 x, u64 y, u64 p) { return x >= y ? x - y : x + (p - y); }
+
+// mode 0: ring (+2^{bw-2}, msb = bit bw-1); mode 1: field (+p/4 mod p, msb = tmp >= p/2+1)
+template <int MODE>
+__global__ __launch_bounds__(256) void pre_kernel(int party, const u64 *__restrict__ in, size_t n, int bw, u64 p,
+                                                  u64 corr_value, int corr_is_not_msb, u64 *__restrict__ tmp,
+                                                  uint8_t *__restrict__ msb, u64 *__restrict__ corr) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64 v = in[i];
+  bool m;
+  if (MODE == 0) {
+    if (party == kAlice) v = (v + (u64(1) << (bw - 2))) & bw_mask(bw);
+    m = (v >> (bw - 1)) & 1;
+  } else {
+    const u64 big = p / 4;
+    if (party == kAlice) v = v >= p - big ? v - p + big : v + big;
+    m = v >= p / 2 + 1;
+  }
+  tmp[i] = v;
+  msb[i] = m;
+  if (party == kAlice && corr) corr[i] = corr_is_not_msb ? (u64)(!m) : (m ? 0 : corr_value);
+}
+
+__global__ __launch_bounds__(256) void r2f_post_kernel(int party, const u64 *__restrict__ tmp,
+                                                       const uint8_t *__restrict__ msb, const u64 *__restrict__ y,
+                                                       size_t n, u64 p, u64 cv, u64 big_mod_p,
+                                                       u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64 yy = y[i];
+  if (party == kAlice) {  // truncation.cpp:551-554
+    const u64 t = secure_sub(0, yy, p);
+    yy = msb[i] ? secure_add(cv, t, p) : t;
+  }
+  u64 o = secure_sub(tmp[i], yy, p);  // :571 / :576
+  if (party == kAlice) o = secure_sub(o, big_mod_p, p);
+  out[i] = o;
+}
+
+// truncating = 0: truncation.cpp:609-611,:626-634; truncating = 1: :667-669,:684-692
+__global__ __launch_bounds__(256) void f2r_post_kernel(int party, const u64 *__restrict__ tmp,
+                                                       const uint8_t *__restrict__ msb, const u64 *__restrict__ y,
+                                                       size_t n, u64 p, int bw, int shift, int truncating,
+                                                       u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 mask = bw_mask(bw), big = p / 4, cv = truncating ? p >> shift : p;
+  u64 yy = y[i];
+  if (party == kAlice) yy = msb[i] ? ((cv - yy) & mask) : ((0 - yy) & mask);
+  u64 o;
+  if (!truncating) o = party == kAlice ? tmp[i] - yy - big : tmp[i] - yy;
+  else o = party == kAlice ? ((tmp[i] - big) >> shift) - yy : (tmp[i] >> shift) - yy + 1;
+  out[i] = o & mask;
+}
+
+// truncation.cpp:353-355,:371-379 (64-bit) and :414-416,:434-442 (128-bit, WIDE)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void r2r_post_kernel(int party, const u64 *__restrict__ tmp,
+                                                       const uint8_t *__restrict__ msb, const u64 *__restrict__ y,
+                                                       size_t n, int bw_a, int bw_b, u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 big = u64(1) << (bw_a - 2);
+  u64 yy = y[i];
+  if (party == kAlice) yy = ((u64)msb[i] - yy) & bw_mask(bw_b - bw_a);
+  if (!WIDE) {
+    u64 o = tmp[i] - (yy << bw_a);
+    if (party == kAlice) o -= big;
+    out[i] = o & bw_mask(bw_b);
+  } else {
+    // 128-bit: (tmp - (yy << bw_a) - big) mod 2^bw_b, bw_a in [2,64], bw_b in (bw_a, 128]
+    const u64 s_lo = bw_a >= 64 ? 0 : yy << bw_a;
+    const u64 s_hi = bw_a >= 64 ? yy : (bw_a == 0 ? 0 : yy >> (64 - bw_a));
+    u64 lo = tmp[i] - s_lo;
+    u64 hi = 0 - s_hi - (tmp[i] < s_lo);
+    if (party == kAlice) {
+      hi -= lo < big;
+      lo -= big;
+    }
+    if (bw_b <= 64) {
+      lo &= bw_mask(bw_b);
+      hi = 0;
+    } else {
+      hi &= bw_mask(bw_b - 64);
+    }
+    out[2 * i] = lo;
+    out[2 * i + 1] = hi;
+  }
+}
+
+// out = (out + (x mod p) * y mod p) mod p with the reference's wrapping u64 addition
+__global__ __launch_bounds__(256) void cross_term_kernel(u64 *__restrict__ out, const u64 *__restrict__ x,
+                                                         const u64 *__restrict__ y, size_t n, u64 p, u64 r_hi,
+                                                         u64 r_lo) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 a = csub(x[i] - mulhi64(x[i], r_hi) * p, p), b = csub(y[i] - mulhi64(y[i], r_hi) * p, p);
+  const u64 m = barrett128(mulhi64(a, b), a * b, p, r_hi, r_lo);
+  const u64 s = out[i] + m;
+  out[i] = csub(s - mulhi64(s, r_hi) * p, p);
+}
+
+static inline unsigned nblocks(size_t n) { return (unsigned)((n + 255) / 256); }
+static int check_common(int party, size_t n, const void *a, const void *b, const void *c) {
+  MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(n == 0 || (a && b && c), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(n <= 0x7fffffffull * 256, MMH_ERR_OUT_BOUND);
+  return MMH_OK;
+}
+}  // namespace mmh
+
+using namespace mmh;
+#define CHECK_RC(x)      \
+  do {                   \
+    int rc_ = (x);       \
+    if (rc_) return rc_; \
+  } while (0)
+#define LAUNCH1D(kern, n, s, ...)                                                          \
+  do {                                                                                     \
+    if ((n) > 0) {                                                                         \
+      hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__); \
+      MMH_HIP(hipGetLastError());                                                          \
+    }                                                                                      \
+  } while (0)
+
+extern "C" int mmh_r2f_pre(int party, const uint64_t *d_in, size_t n, int bw, uint64_t p, uint64_t *d_tmp,
+                           uint8_t *d_msb, uint64_t *d_corr, void *stream) {
+  CHECK_RC(check_common(party, n, d_in, d_tmp, d_msb));
+  MMH_REQUIRE(bw >= 2 && bw <= 64 && p >= 2, MMH_ERR_INVALID_ARG);
+  const u64 mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
+  LAUNCH1D(pre_kernel<0>, n, stream, party, d_in, n, bw, p, mask % p + 1, 0, d_tmp, d_msb, d_corr);
+  return MMH_OK;
+}
+extern "C" int mmh_r2f_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
+                            size_t n, int bw, uint64_t p, uint64_t *d_out, void *stream) {
+  CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
+  MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 2 && bw <= 64 && p >= 2, MMH_ERR_INVALID_ARG);
+  const u64 mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
+  LAUNCH1D(r2f_post_kernel, n, stream, party, d_tmp, d_msb, d_y, n, p, mask % p + 1, (u64(1) << (bw - 2)) % p,
+           d_out);
+  return MMH_OK;
+}
+extern "C" int mmh_f2r_pre(int party, const uint64_t *d_in, size_t n, uint64_t p, int shift, uint64_t *d_tmp,
+                           uint8_t *d_msb, uint64_t *d_corr, void *stream) {
+  CHECK_RC(check_common(party, n, d_in, d_tmp, d_msb));
+  MMH_REQUIRE(p >= 4 && shift >= 0 && shift < 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(pre_kernel<1>, n, stream, party, d_in, n, 0, p, p >> shift, 0, d_tmp, d_msb, d_corr);
+  return MMH_OK;
+}
+extern "C" int mmh_f2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
+                            size_t n, uint64_t p, int bw, uint64_t *d_out, void *stream) {
+  CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
+  MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 1 && bw <= 64 && p >= 4, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(f2r_post_kernel, n, stream, party, d_tmp, d_msb, d_y, n, p, bw, 0, 0, d_out);
+  return MMH_OK;
+}
+extern "C" int mmh_f2r_trunc_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
+                                  size_t n, uint64_t p, int bw, int shift, uint64_t *d_out, void *stream) {
+  CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
+  MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 1 && bw <= 64 && p >= 4 && shift >= 0 && shift < 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(f2r_post_kernel, n, stream, party, d_tmp, d_msb, d_y, n, p, bw, shift, 1, d_out);
+  return MMH_OK;
+}
+extern "C" int mmh_r2r_pre(int party, const uint64_t *d_in, size_t n, int bw_a, uint64_t *d_tmp, uint8_t *d_msb,
+                           uint64_t *d_corr, void *stream) {
+  CHECK_RC(check_common(party, n, d_in, d_tmp, d_msb));
+  MMH_REQUIRE(bw_a >= 2 && bw_a <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(pre_kernel<0>, n, stream, party, d_in, n, bw_a, 2, 0, 1, d_tmp, d_msb, d_corr);
+  return MMH_OK;
+}
+extern "C" int mmh_r2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
+                            size_t n, int bw_a, int bw_b, uint64_t *d_out, void *stream) {
+  CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
+  MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw_a >= 2 && bw_a < bw_b && bw_b <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(r2r_post_kernel<false>, n, stream, party, d_tmp, d_msb, d_y, n, bw_a, bw_b, d_out);
+  return MMH_OK;
+}
+extern "C" int mmh_r2r128_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
+                               size_t n, int bw_a, int bw_b, uint64_t *d_out, void *stream) {
+  CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
+  MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
+  // truncation.cpp:392: the extension is at most 64 bits wide
+  MMH_REQUIRE(bw_a >= 2 && bw_a <= 64 && bw_a < bw_b && bw_b <= 128 && bw_b - bw_a <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(r2r_post_kernel<true>, n, stream, party, d_tmp, d_msb, d_y, n, bw_a, bw_b, d_out);
+  return MMH_OK;
+}
+extern "C" int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n,
+                                   uint64_t p, void *stream) {
+  MMH_REQUIRE(n == 0 || (d_out && d_x && d_y), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(p >= 2 && p < (u64(1) << 62), MMH_ERR_INVALID_ARG);
+  const unsigned __int128 ratio = p & (p - 1) ? ~(unsigned __int128)0 / p : (~(unsigned __int128)0 / p) + 1;
+  LAUNCH1D(cross_term_kernel, n, stream, d_out, d_x, d_y, n, p, (u64)(ratio >> 64), (u64)ratio);
+  return MMH_OK;
+}

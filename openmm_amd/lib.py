@@ -57,6 +57,15 @@ SIGNATURES = {
     "mmh_truncate_and_zero": [_vp, _vp, _sz, _vp, _sz, _vp],
     "mmh_batch_encode": [_vp, _vp, _sz, _vp, _vp],
     "mmh_batch_decode": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_r2f_pre": [_int, _vp, _sz, _int, _u64, _vp, _vp, _vp, _vp],
+    "mmh_r2f_post": [_int, _vp, _vp, _vp, _sz, _int, _u64, _vp, _vp],
+    "mmh_f2r_pre": [_int, _vp, _sz, _u64, _int, _vp, _vp, _vp, _vp],
+    "mmh_f2r_post": [_int, _vp, _vp, _vp, _sz, _u64, _int, _vp, _vp],
+    "mmh_f2r_trunc_post": [_int, _vp, _vp, _vp, _sz, _u64, _int, _int, _vp, _vp],
+    "mmh_r2r_pre": [_int, _vp, _sz, _int, _vp, _vp, _vp, _vp],
+    "mmh_r2r_post": [_int, _vp, _vp, _vp, _sz, _int, _int, _vp, _vp],
+    "mmh_r2r128_post": [_int, _vp, _vp, _vp, _sz, _int, _int, _vp, _vp],
+    "mmh_bole_cross_term": [_vp, _vp, _vp, _sz, _u64, _vp],
 }
 
 
