@@ -175,6 +175,54 @@ int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint6
 int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals, void *stream);
 
 /* =====================================================================================
+ * HomConv2DSS (include/gemini/cheetah/hom_conv2d_ss.h:27-115) as layer-level calls.
+ * A plan fixes the geometry of one layer (HomConv2DSS::Meta: ishape, fshape, n_filters,
+ * padding, stride, is_shared_input) and owns the device index tables derived from
+ * shape_inference::Conv2D, Conv2DSliceHelper and ConvCoeffIndexCalculator.
+ * Tensors are row-major uint64: image C x H x W, filters M x C x fh x fw, result M x oh x ow.
+ * ===================================================================================== */
+typedef struct mmh_conv_meta {
+  int64_t in_c, in_h, in_w;   /* meta.ishape */
+  int64_t f_h, f_w;           /* meta.fshape (channels = in_c) */
+  int64_t n_filters;
+  int32_t padding_same;       /* gemini::Padding: 0 VALID, 1 SAME */
+  int32_t stride;
+  int32_t is_shared_input;
+} mmh_conv_meta;
+typedef struct mmh_conv_plan mmh_conv_plan;
+int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *meta, mmh_conv_plan **out);
+int mmh_conv_plan_destroy(mmh_conv_plan *plan);
+/* counts a caller needs to size buffers: input ciphertexts (= channel slices x spatial slices),
+ * output ciphertexts (= n_filters x spatial slices), result shape, slice_strides */
+int mmh_conv_plan_info(const mmh_conv_plan *plan, size_t *n_in_cts, size_t *n_channel_slices,
+                       size_t *n_spatial_slices, size_t *n_out_cts, int64_t out_shape[3],
+                       int64_t slice_strides[3]);
+/* TensorEncoder::EncodeImageShare (tensor_encoder.cc:178-244): image -> n_in plaintexts [n_in][N] */
+int mmh_conv_encode_image(const mmh_conv_plan *plan, const uint64_t *d_img, uint64_t *d_pts, void *stream);
+/* HomConv2DSS::encodeFilters -> TensorEncoder::EncodeFilter (hom_conv2d_ss.cc:537-561,
+ * tensor_encoder.cc:124-176): filters -> [n_filters][n_channel_slices][N] */
+int mmh_conv_encode_filters(const mmh_conv_plan *plan, const uint64_t *d_filters, uint64_t *d_pts, void *stream);
+/* HomConv2DSS::encryptImage (hom_conv2d_ss.cc:497-522) with injected randomness:
+ * d_a [n_in][L][N] uniform, d_e [n_in][N] signed -> d_cts [n_in][2][L][N] */
+int mmh_conv_encrypt_image(const mmh_conv_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_img,
+                           const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream);
+/* HomConv2DSS::conv2DSS (hom_conv2d_ss.cc:621-712) in the shipped USE_APPROX_RESHARE build:
+ * add_plain of the server's share (when is_shared_input; d_share_pts may be NULL otherwise),
+ * per-filter multiply-accumulate, addRandomMask (flood_ciphertext + approximate
+ * sample_random_mask + sub_poly), truncate_for_decryption, removeUnusedCoeffs.
+ * d_pk_ntt_last: public key restricted to the last level [2][1][N] (NTT form).
+ * Randomness per output ciphertext: d_u ternary [n_out][N], d_e1 noise [n_out][N],
+ * d_mask uniform in [0,q0) [n_out][N].
+ * Outputs: d_out_cts [n_out][2][1][N], d_out_share result tensor M x oh x ow (fully written). */
+int mmh_conv_server(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                    const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                    const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
+                    void *stream);
+/* HomConv2DSS::decryptToTensor (hom_conv2d_ss.cc:853-941): d_sk_ntt at the last level [1][N] */
+int mmh_conv_decrypt(const mmh_conv_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
+                     uint64_t *d_out, void *stream);
+
+/* =====================================================================================
  * Modulus conversion: local share arithmetic of SCI's Truncation class
  * (SCI/src/BuildingBlocks/truncation.h:29-210), split around its single COT call.
  * party: 1 = ALICE (the COT sender, truncation.cpp:549,607,665,351,412), 2 = BOB.

@@ -1,0 +1,349 @@
+// HomConv2DSS on device: tensor <-> polynomial encoders and the fused server / client layer
+// calls (include/gemini/cheetah/hom_conv2d_ss.cc, tensor_encoder.cc).  A plan holds the
+// host-computed geometry (geometry.hpp) as small device tables; every layer call is then a
+// short chain of batched kernels with no per-ciphertext host loop.
+#include "bfv_device.hpp"
+#include "common.hpp"
+#include "geometry.hpp"
+
+namespace mmh {
+int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
+                 int mod_base, hipStream_t s);
+
+// one input window (image polynomial): where it reads the strided image and its zero margins
+struct ImgWindow {
+  int c0, y0, x0;          // first covered entry (strided-image coordinates)
+  int nc, nh, nw;          // window size before mocking
+  int lo_y, hi_y, lo_x, hi_x;
+};
+}  // namespace mmh
+
+struct mmh_conv_plan {
+  const mmh_ctx *ctx = nullptr;
+  mmh_conv_meta meta{};
+  mmh::Dim3 in, f;
+  mmh::ConvSplit split;
+  int sub_h = 1, sub_w = 1;             // Strided3DTensor strides
+  mmh::AxisCut cut_c, cut_h, cut_w;      // cuts of the image that is encoded
+  size_t n_in = 0, n_cslices = 0, n_spatial = 0, n_out = 0;
+  long out_h = 0, out_w = 0;             // result tensor is n_filters x out_h x out_w
+  long filt_origin = 0;                  // FilterIndexer::index_begin for a full channel window
+  size_t n_targets = 0;                  // targets summed over the spatial windows
+  // device tables
+  mmh::ImgWindow *d_windows = nullptr;   // [n_in]
+  uint32_t *d_tgt_coef = nullptr;        // [n_targets] coefficient index
+  uint32_t *d_tgt_dst = nullptr;         // [n_targets] offset inside one out_h x out_w plane
+  uint32_t *d_tgt_slice = nullptr;       // [n_targets] spatial window the target belongs to
+  uint8_t *d_keep = nullptr;             // [n_spatial][N] coefficients that survive remove_unused_coeffs
+  std::vector<void *> allocs;
+};
+
+namespace mmh {
+__device__ __forceinline__ u64 red_t(u64 v, const ModC &t) { return barrett128(0, v, t.q, t.barrett_hi, t.barrett_lo); }
+
+// EncodeImageShare: polynomial w, coefficient (c, y, x) of the mocked window
+__global__ __launch_bounds__(256) void encode_image_kernel(const u64 *__restrict__ img, u64 *__restrict__ polys,
+                                                           const ImgWindow *__restrict__ wins, size_t n_in, int logN,
+                                                           int wc, int wh, int ww, int H, int W, int sub_h, int sub_w,
+                                                           ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_in << logN)) return;
+  const size_t k = idx >> logN;
+  const int i = (int)(idx & ((size_t(1) << logN) - 1));
+  u64 v = 0;
+  if (i < wc * wh * ww) {
+    const ImgWindow g = wins[k];
+    const int c = i / (wh * ww), y = (i / ww) % wh, x = i % ww;
+    if (c < g.nc && y >= g.lo_y && y + g.hi_y < g.nh && x >= g.lo_x && x + g.hi_x < g.nw) {
+      const size_t cc = c + g.c0, yy = (size_t)(y - g.lo_y + g.y0) * sub_h, xx = (size_t)(x - g.lo_x + g.x0) * sub_w;
+      v = red_t(img[(cc * H + yy) * W + xx], t);
+    }
+  }
+  polys[idx] = v;
+}
+
+// EncodeFilter: scatter filter m, channel c, tap (r, col) to its reversed coefficient
+__global__ __launch_bounds__(256) void encode_filter_kernel(const u64 *__restrict__ filt, u64 *__restrict__ polys,
+                                                            size_t total, int logN, int C, int fh, int fw, int wc,
+                                                            int n_cslices, long origin, long plane, long row, ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [M][C][fh][fw]
+  if (idx >= total) return;
+  const int col = (int)(idx % fw), r = (int)((idx / fw) % fh);
+  const size_t mc = idx / ((size_t)fw * fh);
+  const int c = (int)(mc % C);
+  const size_t m = mc / C;
+  const int slice = c / wc, cc = c % wc;
+  const long coef = origin - cc * plane - r * row - col;
+  polys[((m * n_cslices + slice) << logN) + coef] = red_t(filt[idx], t);
+}
+
+// share tensor from the RNS mask: out[m][dst] = scale_and_round(r[m*S + slice][coef])
+__global__ __launch_bounds__(256) void share_from_mask_kernel(const u64 *__restrict__ r, u64 *__restrict__ out,
+                                                              size_t n_filters, size_t n_targets, size_t n_spatial,
+                                                              size_t plane, int logN, const u32 *__restrict__ coef,
+                                                              const u32 *__restrict__ dst, const u32 *__restrict__ slice,
+                                                              BfvConsts b, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_filters * n_targets) return;
+  const size_t m = idx / n_targets, g = idx % n_targets;
+  const u64 x[2] = {r[((m * n_spatial + slice[g]) << logN) + coef[g]], 0};  // last level: one limb
+  out[m * plane + dst[g]] = behz_round(x, b, b.lv[1], mods);
+}
+// gather decrypted coefficients: out[m][dst] = pts[m*S + slice][coef]
+__global__ __launch_bounds__(256) void gather_targets_kernel(const u64 *__restrict__ pts, u64 *__restrict__ out,
+                                                             size_t n_filters, size_t n_targets, size_t n_spatial,
+                                                             size_t plane, int logN, const u32 *__restrict__ coef,
+                                                             const u32 *__restrict__ dst,
+                                                             const u32 *__restrict__ slice) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_filters * n_targets) return;
+  const size_t m = idx / n_targets, g = idx % n_targets;
+  out[m * plane + dst[g]] = pts[((m * n_spatial + slice[g]) << logN) + coef[g]];
+}
+
+template <class T>
+static int upload_vec(mmh_conv_plan *p, const std::vector<T> &v, T **d) {
+  MMH_HIP(hipMalloc((void **)d, std::max<size_t>(1, v.size()) * sizeof(T)));
+  p->allocs.push_back(*d);
+  if (!v.empty()) MMH_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MMH_OK;
+}
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+}  // namespace mmh
+
+using namespace mmh;
+#define CHECK_RC(x)      \
+  do {                   \
+    int rc_ = (x);       \
+    if (rc_) return rc_; \
+  } while (0)
+
+extern "C" int mmh_conv_plan_destroy(mmh_conv_plan *p) {
+  if (!p) return MMH_OK;
+  for (void *a : p->allocs) (void)hipFree(a);
+  delete p;
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *meta, mmh_conv_plan **out) {
+  MMH_REQUIRE(ctx && meta && out, MMH_ERR_NULL_POINTER);
+  *out = nullptr;
+  MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
+  const long N = (long)ctx->N;
+  const Dim3 in{meta->in_c, meta->in_h, meta->in_w}, f{meta->in_c, meta->f_h, meta->f_w};
+  MMH_REQUIRE(in.count() > 0 && f.count() > 0 && meta->n_filters > 0 && meta->stride >= 1, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(f.h * f.w <= N, MMH_ERR_INVALID_ARG);
+  const bool same = meta->padding_same != 0;
+  const long stride = meta->stride;
+  const ConvSplit sp = conv_split(N, in, f, same, stride);
+  MMH_REQUIRE(sp.ok, MMH_ERR_INVALID_ARG);                       // EncodeImageShare: shape_inference failed
+  MMH_REQUIRE(sp.win_h >= f.h && sp.win_w >= f.h, MMH_ERR_INVALID_ARG);  // sliced_3d_tensor.h:148-149
+  MMH_REQUIRE(sp.win_c * sp.win_h * sp.win_w <= N, MMH_ERR_OUT_BOUND);
+  // result shape (shape_inference.cc:28-52)
+  const long oh = (sp.padded_shape.h - f.h + stride) / stride, ow = (sp.padded_shape.w - f.w + stride) / stride;
+  MMH_REQUIRE(oh > 0 && ow > 0, MMH_ERR_CONFIG);
+
+  mmh_conv_plan *p = new mmh_conv_plan();
+  p->ctx = ctx;
+  p->meta = *meta;
+  p->in = in;
+  p->f = f;
+  p->split = sp;
+  p->out_h = oh;
+  p->out_w = ow;
+  // Strided3DTensor (tensor_encoder.cc:197-204): subsample where the split shrank the axis
+  p->sub_h = sp.strided_shape.h < in.h ? (int)stride : 1;
+  p->sub_w = sp.strided_shape.w < in.w ? (int)stride : 1;
+  const Dim3 simg{in.c, (in.h + p->sub_h - 1) / p->sub_h, (in.w + p->sub_w - 1) / p->sub_w};
+  p->cut_c.init(simg.c, 0, sp.win_c, f.c, false);
+  p->cut_h.init(simg.h, sp.pad_h, sp.win_h, f.h, true);
+  p->cut_w.init(simg.w, sp.pad_w, sp.win_w, f.w, true);
+  p->n_cslices = (size_t)p->cut_c.count;
+  p->n_spatial = (size_t)(p->cut_h.count * p->cut_w.count);
+  p->n_in = p->n_cslices * p->n_spatial;
+  p->n_out = (size_t)meta->n_filters * p->n_spatial;
+  // FilterIndexer (tensor_encoder.cc:78-84): "h" is taken from the filter WIDTH
+  p->filt_origin = sp.win_h * sp.win_w * (sp.win_c - 1) + sp.win_w * (f.w - 1) + f.w - 1;
+  int rc = MMH_OK;
+  auto fail = [&](int code, const char *msg) {
+    mmh_conv_plan_destroy(p);
+    set_error(std::string("mmh_conv_plan_create: ") + msg);
+    return code;
+  };
+  if (p->filt_origin >= N || p->filt_origin - (sp.win_c - 1) * sp.win_h * sp.win_w - (f.h - 1) * sp.win_w - (f.w - 1) < 0)
+    return fail(MMH_ERR_OUT_BOUND, "filter coefficient index out of range");
+
+  std::vector<ImgWindow> wins(p->n_in);
+  for (size_t i = 0; i < p->n_in; ++i) {
+    const long kc = (long)(i / p->n_spatial), kh = (long)((i % p->n_spatial) / p->cut_w.count),
+               kw = (long)(i % p->cut_w.count);
+    long c0, y0, x0, lo, hi;
+    ImgWindow g{};
+    if (!p->cut_c.clip(kc, c0, lo, hi)) return fail(MMH_ERR_INTERNAL, "empty channel window");
+    g.c0 = (int)c0;
+    g.nc = (int)p->cut_c.size(kc);
+    if (!p->cut_h.clip(kh, y0, lo, hi)) return fail(MMH_ERR_INTERNAL, "empty row window");
+    g.y0 = (int)y0, g.lo_y = (int)lo, g.hi_y = (int)hi, g.nh = (int)p->cut_h.size(kh);
+    if (!p->cut_w.clip(kw, x0, lo, hi)) return fail(MMH_ERR_INTERNAL, "empty column window");
+    g.x0 = (int)x0, g.lo_x = (int)lo, g.hi_x = (int)hi, g.nw = (int)p->cut_w.size(kw);
+    wins[i] = g;
+  }
+  // Output targets: the index calculator that addRandomMask / decryptToTensor build
+  // (hom_conv2d_ss.cc:738-744, :874-880): on the subsampled shape with stride 1 when the input
+  // was compressed, else on the original shape with the real stride.  Its cuts equal ours.
+  const bool compressed = sp.strided_shape.count() < in.count();
+  const long out_stride = compressed ? 1 : stride;
+  std::vector<u32> coef, dst, slice;
+  std::vector<uint8_t> keep(p->n_spatial * (size_t)N, 0);
+  long hoff = 0;
+  for (long kh = 0; kh < p->cut_h.count; ++kh) {
+    long woff = 0, last_h = 0;
+    for (long kw = 0; kw < p->cut_w.count; ++kw) {
+      const size_t s = (size_t)(kh * p->cut_w.count + kw);
+      const OutWindow o = out_window(p->cut_h, p->cut_w, kh, kw, f, out_stride);
+      for (long y = 0; y < o.out_h; ++y)
+        for (long x = 0; x < o.out_w; ++x) {
+          const long r = y * out_stride + o.first_r, c = x * out_stride + o.first_c;
+          if (r >= sp.win_h || c >= sp.win_w) return fail(MMH_ERR_OUT_BOUND, "target outside the window");
+          if (hoff + y >= oh || woff + x >= ow) return fail(MMH_ERR_DIM_MISMATCH, "windows overrun the result");
+          coef.push_back((u32)(p->filt_origin + r * sp.win_w + c));
+          dst.push_back((u32)((hoff + y) * ow + woff + x));
+          slice.push_back((u32)s);
+        }
+      // removeUnusedCoeffs (hom_conv2d_ss.cc:817-819) always indexes with stride 1, VALID, on the
+      // padded strided shape: a superset of the targets when stride > 1 without compression
+      const OutWindow k1 = out_window(p->cut_h, p->cut_w, kh, kw, f, 1);
+      for (long y = 0; y < k1.out_h; ++y)
+        for (long x = 0; x < k1.out_w; ++x) keep[s * N + p->filt_origin + y * sp.win_w + x] = 1;
+      woff += o.out_w;
+      last_h = o.out_h;
+    }
+    hoff += last_h;
+  }
+  p->n_targets = coef.size();
+  if ((rc = upload_vec(p, wins, &p->d_windows)) || (rc = upload_vec(p, coef, &p->d_tgt_coef)) ||
+      (rc = upload_vec(p, dst, &p->d_tgt_dst)) || (rc = upload_vec(p, slice, &p->d_tgt_slice)) ||
+      (rc = upload_vec(p, keep, &p->d_keep))) {
+    mmh_conv_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_plan_info(const mmh_conv_plan *p, size_t *n_in_cts, size_t *n_channel_slices,
+                                  size_t *n_spatial_slices, size_t *n_out_cts, int64_t out_shape[3],
+                                  int64_t slice_strides[3]) {
+  MMH_REQUIRE(p, MMH_ERR_NULL_POINTER);
+  if (n_in_cts) *n_in_cts = p->n_in;
+  if (n_channel_slices) *n_channel_slices = p->n_cslices;
+  if (n_spatial_slices) *n_spatial_slices = p->n_spatial;
+  if (n_out_cts) *n_out_cts = p->n_out;
+  if (out_shape) out_shape[0] = p->meta.n_filters, out_shape[1] = p->out_h, out_shape[2] = p->out_w;
+  if (slice_strides) slice_strides[0] = p->split.win_c, slice_strides[1] = p->split.win_h, slice_strides[2] = p->split.win_w;
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_encode_image(const mmh_conv_plan *p, const uint64_t *d_img, uint64_t *d_pts, void *stream) {
+  MMH_REQUIRE(p && d_img && d_pts, MMH_ERR_NULL_POINTER);
+  const mmh_ctx *ctx = p->ctx;
+  const size_t total = p->n_in << ctx->logN;
+  hipLaunchKernelGGL(encode_image_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, d_img, d_pts,
+                     p->d_windows, p->n_in, ctx->logN, (int)p->split.win_c, (int)p->split.win_h, (int)p->split.win_w,
+                     (int)p->in.h, (int)p->in.w, p->sub_h, p->sub_w, ctx->bfv.t);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_encode_filters(const mmh_conv_plan *p, const uint64_t *d_filters, uint64_t *d_pts,
+                                       void *stream) {
+  MMH_REQUIRE(p && d_filters && d_pts, MMH_ERR_NULL_POINTER);
+  const mmh_ctx *ctx = p->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n_polys = (size_t)p->meta.n_filters * p->n_cslices;
+  MMH_HIP(hipMemsetAsync(d_pts, 0, (n_polys << ctx->logN) * 8, s));
+  const size_t total = (size_t)p->meta.n_filters * p->f.count();
+  hipLaunchKernelGGL(encode_filter_kernel, dim3(nblk(total)), dim3(256), 0, s, d_filters, d_pts, total, ctx->logN,
+                     (int)p->f.c, (int)p->f.h, (int)p->f.w, (int)p->split.win_c, (int)p->n_cslices, p->filt_origin,
+                     p->split.win_h * p->split.win_w, p->split.win_w, ctx->bfv.t);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_encrypt_image(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_img,
+                                      const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  MMH_REQUIRE(p && d_sk_ntt && d_img && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (p->n_in << p->ctx->logN) * 8, s));
+  int rc = mmh_conv_encode_image(p, d_img, (u64 *)pts, stream);
+  if (!rc) rc = mmh_encrypt_symmetric(p->ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, p->n_in, d_cts, stream);
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}
+
+extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                               const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                               const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                               uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(p && d_in_cts && d_filter_pts && d_pk_ntt_last && d_u && d_e1 && d_mask && d_out_cts && d_out_share,
+              MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
+  const mmh_ctx *ctx = p->ctx;
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
+  void *image = nullptr, *acc = nullptr, *zero = nullptr;
+  int rc = MMH_OK;
+  auto cleanup = [&]() {
+    if (image) (void)hipFreeAsync(image, s);
+    if (acc) (void)hipFreeAsync(acc, s);
+    if (zero) (void)hipFreeAsync(zero, s);
+  };
+  const u64 *cts = d_in_cts;
+  if (p->meta.is_shared_input) {  // conv2DSS :655-671: image = share0 + Delta*share1
+    MMH_HIP(hipMallocAsync(&image, p->n_in * 4 * N * 8, s));
+    rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
+    cts = (const u64 *)image;
+  }
+  if (!rc && hipMallocAsync(&acc, p->n_out * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && hipMallocAsync(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
+  if (!rc) rc = mmh_mul_plain_acc(ctx, 0, cts, p->n_in, d_filter_pts, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
+  // addRandomMask :761-788: flood_ciphertext (mod-switch + pk-encryption of zero without e0),
+  if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
+  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, nullptr, d_e1, p->n_out, (u64 *)zero, stream);
+  if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
+  // ... sample_random_mask (approximate re-sharing) + sub_poly_inplace, share scattered into the tensor
+  if (!rc) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
+  if (!rc) {
+    const size_t total = M * p->n_targets;
+    hipLaunchKernelGGL(share_from_mask_kernel, dim3(nblk(total)), dim3(256), 0, s, d_mask, d_out_share, M,
+                       p->n_targets, S, (size_t)(p->out_h * p->out_w), ctx->logN, p->d_tgt_coef, p->d_tgt_dst,
+                       p->d_tgt_slice, ctx->bfv, ctx->d_mods);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  // truncate_for_decryption :698-703 and removeUnusedCoeffs :800-851 in one pass
+  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, S, stream);
+  cleanup();
+  return rc;
+}
+
+extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
+                                uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(p && d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
+  const mmh_ctx *ctx = p->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (p->n_out << ctx->logN) * 8, s));
+  int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, p->n_out, (u64 *)pts, stream);
+  if (!rc) {
+    const size_t M = (size_t)p->meta.n_filters, total = M * p->n_targets;
+    hipLaunchKernelGGL(gather_targets_kernel, dim3(nblk(total)), dim3(256), 0, s, (const u64 *)pts, d_out, M,
+                       p->n_targets, p->n_spatial, (size_t)(p->out_h * p->out_w), ctx->logN, p->d_tgt_coef,
+                       p->d_tgt_dst, p->d_tgt_slice);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}

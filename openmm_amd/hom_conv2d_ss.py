@@ -1,0 +1,161 @@
+"""Host-side mirror of ``gemini::HomConv2DSS`` (include/gemini/cheetah/hom_conv2d_ss.h:27-115).
+
+Same method names, argument meaning and error codes as the reference class; ciphertexts and
+plaintexts are device tensors ([n,2,limbs,N] / [n,N] int64 holding uint64 bits) instead of
+``seal::Ciphertext`` / ``seal::Plaintext`` vectors, and the per-ciphertext thread-pool loops
+are single batched calls into libmm_hip.  Randomness is passed in explicitly (``rand``) so a
+caller -- or a parity test -- controls every sampled polynomial.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+from . import lib as L
+
+VALID, SAME = 0, 1  # gemini::Padding (tensor_shape.h:11)
+
+
+class ConvMetaC(C.Structure):
+    _fields_ = [("in_c", C.c_int64), ("in_h", C.c_int64), ("in_w", C.c_int64), ("f_h", C.c_int64),
+                ("f_w", C.c_int64), ("n_filters", C.c_int64), ("padding_same", C.c_int32),
+                ("stride", C.c_int32), ("is_shared_input", C.c_int32)]
+
+
+@dataclass
+class Meta:
+    """HomConv2DSS::Meta (hom_conv2d_ss.h:31-38)"""
+    ishape: tuple            # (C, H, W)
+    fshape: tuple            # (C, fh, fw)
+    n_filters: int
+    padding: int = VALID
+    stride: int = 1
+    is_shared_input: bool = True
+
+
+class Plan:
+    """geometry of one layer on the device (mmh_conv_plan)"""
+
+    def __init__(self, ctx, meta):
+        self.ctx, self.meta = ctx, meta
+        if len(meta.ishape) != 3 or len(meta.fshape) != 3 or meta.ishape[0] != meta.fshape[0]:
+            raise L.MMHError(7, "Conv2D: channels mismatch")
+        m = ConvMetaC(meta.ishape[0], meta.ishape[1], meta.ishape[2], meta.fshape[1], meta.fshape[2],
+                      meta.n_filters, int(meta.padding), int(meta.stride), int(meta.is_shared_input))
+        self.handle = L._vp()
+        L.check(ctx.lib.mmh_conv_plan_create(ctx.handle, C.byref(m), C.byref(self.handle)))
+        a, b, c, d = L._sz(), L._sz(), L._sz(), L._sz()
+        oshape, strides = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+        L.check(ctx.lib.mmh_conv_plan_info(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), oshape,
+                                           strides))
+        self.n_in, self.n_cslices, self.n_spatial, self.n_out = a.value, b.value, c.value, d.value
+        self.out_shape = tuple(int(x) for x in oshape)
+        self.slice_strides = tuple(int(x) for x in strides)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ctx.lib.mmh_conv_plan_destroy(self.handle)
+                self.handle = L._vp()
+        except Exception:
+            pass
+
+
+class HomConv2DSS:
+    def __init__(self):
+        self.ctx = self.sk_ntt = self.pk_ntt = None
+        self._plans = {}
+
+    # HomConv2DSS::setUp (hom_conv2d_ss.cc:467-495): sk_ntt [L,N] (client), pk_ntt [2,L,N] (server)
+    def setUp(self, ctx, sk_ntt=None, pk_ntt=None):
+        self.ctx, self.sk_ntt, self.pk_ntt = ctx, sk_ntt, pk_ntt
+        self.pk_last = None if pk_ntt is None else pk_ntt[:, :1].contiguous()
+        self.sk_last = None if sk_ntt is None else sk_ntt[:1].contiguous()
+        return 0
+
+    def plan(self, meta):
+        key = (tuple(meta.ishape), tuple(meta.fshape), meta.n_filters, meta.padding, meta.stride,
+               meta.is_shared_input)
+        if key not in self._plans:
+            self._plans[key] = Plan(self.ctx, meta)
+        return self._plans[key]
+
+    def _need(self, cond, code, what):
+        if not cond:
+            raise L.MMHError(code, what)
+
+    # encryptImage (hom_conv2d_ss.cc:497-522); rand = (a [n_in,L,N] uniform, e [n_in,N] signed)
+    def encryptImage(self, img, meta, rand):
+        self._need(self.ctx is not None and self.sk_ntt is not None, 1, "encryptImage: no secret key")
+        self._need(tuple(img.shape) == tuple(meta.ishape), 3, "encryptImage: image shape")
+        p = self.plan(meta)
+        a, e = rand
+        out = self.ctx._empty(p.n_in, 2, self.ctx.L, self.ctx.N)
+        L.check(self.ctx.lib.mmh_conv_encrypt_image(p.handle, L.dptr(self.sk_ntt), L.dptr(img), L.dptr(a),
+                                                    L.dptr(e), L.dptr(out), L._stream_ptr()))
+        return out
+
+    # encodeImage (hom_conv2d_ss.cc:524-535)
+    def encodeImage(self, img, meta):
+        self._need(self.ctx is not None, 1, "encodeImage: no context")
+        self._need(tuple(img.shape) == tuple(meta.ishape), 3, "encodeImage: image shape")
+        p = self.plan(meta)
+        out = self.ctx._empty(p.n_in, self.ctx.N)
+        L.check(self.ctx.lib.mmh_conv_encode_image(p.handle, L.dptr(img), L.dptr(out), L._stream_ptr()))
+        return out
+
+    # encodeFilters (hom_conv2d_ss.cc:537-561): filters [M, C, fh, fw] -> [M, n_cslices, N]
+    def encodeFilters(self, filters, meta):
+        self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
+        self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
+        p = self.plan(meta)
+        out = self.ctx._empty(meta.n_filters, p.n_cslices, self.ctx.N)
+        L.check(self.ctx.lib.mmh_conv_encode_filters(p.handle, L.dptr(filters), L.dptr(out), L._stream_ptr()))
+        return out
+
+    # conv2DSS (hom_conv2d_ss.cc:621-712); rand = (u [n_out,N], e1 [n_out,N], mask [n_out,N])
+    def conv2DSS(self, img_share0, img_share1, filters, meta, rand):
+        self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
+        p = self.plan(meta)
+        self._need(filters.shape[0] == meta.n_filters, 3, "conv2DSS: #filters")
+        self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
+        if meta.is_shared_input:
+            self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
+        # conv2DOneFilter :573-580: a filter whose polynomials are all zero is an error
+        nz = (filters.reshape(meta.n_filters, -1) != 0).any(dim=1)
+        self._need(bool(nz.all()), 8, "conv2DOneFilter: filter with all zero is not supported")
+        u, e1, mask = rand
+        out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
+        out_share = self.ctx._empty(*p.out_shape)
+        L.check(self.ctx.lib.mmh_conv_server(p.handle, L.dptr(img_share0),
+                                             L.dptr(img_share1 if meta.is_shared_input else None),
+                                             L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
+                                             L.dptr(mask), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        return out_cts, out_share
+
+    # decryptToTensor (hom_conv2d_ss.cc:853-941)
+    def decryptToTensor(self, enc_tensor, meta):
+        self._need(self.sk_ntt is not None, 1, "decrypt without sk")
+        p = self.plan(meta)
+        self._need(enc_tensor.shape[0] == p.n_out, 8, "decryptToTensor: #ciphertexts")
+        out = self.ctx._empty(*p.out_shape)
+        L.check(self.ctx.lib.mmh_conv_decrypt(p.handle, L.dptr(self.sk_last), L.dptr(enc_tensor), L.dptr(out),
+                                              L._stream_ptr()))
+        return out
+
+    # idealFunctionality (hom_conv2d_ss.cc:975-1012; Tensor::Conv2D tensor.h:274-362), mod 2^k only
+    def idealFunctionality(self, in_tensor, filters, meta):
+        import torch
+        t = self.ctx.t
+        C_, H, W = meta.ishape
+        fh, fw = meta.fshape[1:]
+        ph = (fh - 1) if meta.padding == SAME else 0
+        pw = (fw - 1) if meta.padding == SAME else 0
+        top, left = (ph + 1) // 2, (pw + 1) // 2
+        x = torch.zeros((C_, H + ph, W + pw), dtype=torch.int64, device=in_tensor.device)
+        x[:, top:top + H, left:left + W] = in_tensor
+        oh, ow = (H + ph - fh + meta.stride) // meta.stride, (W + pw - fw + meta.stride) // meta.stride
+        out = torch.zeros((meta.n_filters, oh, ow), dtype=torch.int64, device=in_tensor.device)
+        for r in range(fh):
+            for c in range(fw):
+                patch = x[:, r:r + (oh - 1) * meta.stride + 1:meta.stride, c:c + (ow - 1) * meta.stride + 1:meta.stride]
+                out += (filters[:, :, r, c, None, None] * patch[None]).sum(1)  # int64 wraps mod 2^64
+        return out & (t - 1) if t & (t - 1) == 0 else out

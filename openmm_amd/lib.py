@@ -57,6 +57,15 @@ SIGNATURES = {
     "mmh_truncate_and_zero": [_vp, _vp, _sz, _vp, _sz, _vp],
     "mmh_batch_encode": [_vp, _vp, _sz, _vp, _vp],
     "mmh_batch_decode": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_conv_plan_create": [_vp, _vp, C.POINTER(_vp)],
+    "mmh_conv_plan_destroy": [_vp],
+    "mmh_conv_plan_info": [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz),
+                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "mmh_conv_encode_image": [_vp, _vp, _vp, _vp],
+    "mmh_conv_encode_filters": [_vp, _vp, _vp, _vp],
+    "mmh_conv_encrypt_image": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
     "mmh_r2f_pre": [_int, _vp, _sz, _int, _u64, _vp, _vp, _vp, _vp],
     "mmh_r2f_post": [_int, _vp, _vp, _vp, _sz, _int, _u64, _vp, _vp],
     "mmh_f2r_pre": [_int, _vp, _sz, _u64, _int, _vp, _vp, _vp, _vp],

@@ -171,6 +171,24 @@ void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, si
 uint64_t mmo_modulo_mult(uint64_t a, uint64_t b, uint64_t mod);
 void mmo_bole_cross_term(uint64_t *out, const uint64_t *x, const uint64_t *y, size_t n, uint64_t p);
 
+/* ---- tensor <-> polynomial geometry (mm_geom_oracle.c) ---- */
+int  mmo_conv_out_shape(const long ishape[3], const long fshape[3], int same, int stride, long out_hw[2]);
+int  mmo_conv_shape_infer(long N, const long ishape[3], const long fshape[3], int same, int stride,
+                          long strided[3], int pads[2], int slice_strides[3]);
+long mmo_conv_encode_image(long N, uint64_t t, const uint64_t *img, const long ishape[3], const long fshape[3],
+                           int same, int stride, uint64_t *polys);
+long mmo_conv_encode_filter(long N, uint64_t t, const uint64_t *filter, const long ishape[3], const long fshape[3],
+                            int same, int stride, uint64_t *polys);
+typedef struct mmo_conv_indexer mmo_conv_indexer;
+mmo_conv_indexer *mmo_conv_indexer_create(long N, const long ishape[3], const long fshape[3], int same, int stride);
+void mmo_conv_indexer_destroy(mmo_conv_indexer *x);
+int  mmo_conv_indexer_slices(const mmo_conv_indexer *x, int d);
+int  mmo_conv_indexer_get(const mmo_conv_indexer *x, int sh, int sw, long out_hw[2], uint64_t *indices);
+void mmo_fc_split(long nrows, long ncols, long N, long split[2]);
+long mmo_fc_encode_input(long N, uint64_t t, const uint64_t *vec, long len_total, long d1, uint64_t *polys);
+long mmo_fc_encode_weights(long N, uint64_t t, const uint64_t *W, long nrows, long ncols, long d0, long d1,
+                           uint64_t *polys);
+
 /* ---- timed CPU baseline helpers (bench.py cpu_baseline leg): OpenMP over independent polys */
 void mmo_ntt_forward_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
 void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);

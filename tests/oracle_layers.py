@@ -1,0 +1,202 @@
+"""Reference-shaped layer flows composed from oracle primitives (CPU, slow, small shapes):
+the loops of hom_conv2d_ss.cc / hom_fc_ss.cc / hom_bn_ss.cc written out one ciphertext at a
+time, exactly as the reference schedules them."""
+import ctypes as C
+
+import numpy as np
+
+from tests.oracle_binding import A, load
+
+c_long3 = C.c_long * 3
+
+
+def _l3(x):
+    return c_long3(*[int(v) for v in x])
+
+
+def setup_geom(lib):
+    if getattr(lib, "_geom_ready", False):
+        return
+    vp, ci, cl, u64 = C.c_void_p, C.c_int, C.c_long, C.c_uint64
+    lib.mmo_conv_out_shape.argtypes = [c_long3, c_long3, ci, ci, C.POINTER(cl)]
+    lib.mmo_conv_shape_infer.argtypes = [cl, c_long3, c_long3, ci, ci, C.POINTER(cl), C.POINTER(ci), C.POINTER(ci)]
+    lib.mmo_conv_encode_image.restype = cl
+    lib.mmo_conv_encode_image.argtypes = [cl, u64, vp, c_long3, c_long3, ci, ci, vp]
+    lib.mmo_conv_encode_filter.restype = cl
+    lib.mmo_conv_encode_filter.argtypes = [cl, u64, vp, c_long3, c_long3, ci, ci, vp]
+    lib.mmo_conv_indexer_create.restype = vp
+    lib.mmo_conv_indexer_create.argtypes = [cl, c_long3, c_long3, ci, ci]
+    lib.mmo_conv_indexer_destroy.argtypes = [vp]
+    lib.mmo_conv_indexer_slices.argtypes = [vp, ci]
+    lib.mmo_conv_indexer_get.argtypes = [vp, ci, ci, C.POINTER(cl), vp]
+    lib.mmo_fc_split.argtypes = [cl, cl, cl, C.POINTER(cl)]
+    lib.mmo_fc_encode_input.restype = cl
+    lib.mmo_fc_encode_input.argtypes = [cl, u64, vp, cl, cl, vp]
+    lib.mmo_fc_encode_weights.restype = cl
+    lib.mmo_fc_encode_weights.argtypes = [cl, u64, vp, cl, cl, cl, cl, vp]
+    lib._geom_ready = True
+
+
+class ConvOracle:
+    """HomConv2DSS flow for one Meta on the oracle context `o`."""
+
+    def __init__(self, o, ishape, fshape, n_filters, same, stride, shared):
+        self.o, self.lib = o, load()
+        setup_geom(self.lib)
+        self.ishape, self.fshape, self.M = tuple(ishape), tuple(fshape), n_filters
+        self.same, self.stride, self.shared = int(same), int(stride), shared
+        N = o.N
+        strided, pads, ss = (C.c_long * 3)(), (C.c_int * 2)(), (C.c_int * 3)()
+        rc = self.lib.mmo_conv_shape_infer(N, _l3(ishape), _l3(fshape), self.same, self.stride, strided, pads, ss)
+        assert rc == 0, "shape inference failed"
+        self.strided, self.pads, self.slice_strides = tuple(strided), tuple(pads), tuple(ss)
+        ohw = (C.c_long * 2)()
+        assert self.lib.mmo_conv_out_shape(_l3(ishape), _l3(fshape), self.same, self.stride, ohw) == 0
+        self.out_shape = (n_filters, ohw[0], ohw[1])
+        self.n_in = self.lib.mmo_conv_encode_image(N, o.t, None, _l3(ishape), _l3(fshape), self.same, self.stride, None)
+        self.n_cs = self.lib.mmo_conv_encode_filter(N, o.t, None, _l3(ishape), _l3(fshape), self.same, self.stride, None)
+        self.n_sp = self.n_in // self.n_cs
+        self.n_out = n_filters * self.n_sp
+        compressed = int(np.prod(self.strided)) < int(np.prod(ishape))
+        # hom_conv2d_ss.cc:741-744 / :877-880
+        self.mask_ix = self._indexer(self.strided if compressed else ishape, 0 if compressed else self.same,
+                                     1 if compressed else self.stride)
+        # hom_conv2d_ss.cc:817-819
+        self.keep_ix = self._indexer(self.strided, 0, 1)
+
+    def _indexer(self, shape, same, stride):
+        h = self.lib.mmo_conv_indexer_create(self.o.N, _l3(shape), _l3(self.fshape), int(same), int(stride))
+        assert h
+        return h
+
+    def targets(self, ix, sh, sw):
+        hw = (C.c_long * 2)()
+        assert self.lib.mmo_conv_indexer_get(ix, sh, sw, hw, None) == 0
+        idx = np.zeros(hw[0] * hw[1], np.uint64)
+        assert self.lib.mmo_conv_indexer_get(ix, sh, sw, hw, A(idx)) == 0
+        return (hw[0], hw[1]), idx
+
+    def encode_image(self, img):
+        out = np.zeros((self.n_in, self.o.N), np.uint64)
+        img = np.ascontiguousarray(img, np.uint64)
+        n = self.lib.mmo_conv_encode_image(self.o.N, self.o.t, A(img), _l3(self.ishape), _l3(self.fshape), self.same,
+                                           self.stride, A(out))
+        assert n == self.n_in
+        return out
+
+    def encode_filters(self, filters):
+        out = np.zeros((self.M, self.n_cs, self.o.N), np.uint64)
+        for m in range(self.M):
+            f = np.ascontiguousarray(filters[m], np.uint64)
+            n = self.lib.mmo_conv_encode_filter(self.o.N, self.o.t, A(f), _l3(self.ishape), _l3(self.fshape),
+                                                self.same, self.stride, A(out[m]))
+            assert n == self.n_cs
+        return out
+
+    def encrypt_image(self, sk, img, a, e):
+        pts = self.encode_image(img)
+        cts = np.zeros((self.n_in, 2, self.o.L, self.o.N), np.uint64)
+        for k in range(self.n_in):
+            self.lib.mmo_encrypt_symmetric(self.o.p, 0, A(sk), A(a[k]), A(e[k]), A(pts[k]), self.o.N, A(cts[k]))
+        return cts
+
+    def server(self, in_cts, share_pts, filter_pts, pk1, u, e1, mask):
+        """conv2DSS, USE_APPROX_RESHARE build"""
+        o, lib, N, L = self.o, self.lib, self.o.N, self.o.L
+        image = in_cts.copy()
+        if self.shared:
+            for k in range(self.n_in):                                   # :655-671
+                lib.mmo_add_plain(o.p, 0, A(image[k]), A(share_pts[k]), N)
+        out = np.zeros((self.n_out, 2, L, N), np.uint64)
+        tmp = np.zeros((2, L, N), np.uint64)
+        for m in range(self.M):                                          # conv2DOneFilter :563-619
+            started = [False] * self.n_sp
+            for c in range(self.n_cs):
+                if not filter_pts[m, c].any():
+                    continue
+                for i in range(self.n_sp):
+                    ii = c * self.n_sp + i
+                    dst = out[m * self.n_sp + i]
+                    if started[i]:
+                        lib.mmo_multiply_plain(o.p, 0, A(image[ii]), A(filter_pts[m, c]), N, A(tmp))
+                        lib.mmo_ct_add(o.p, 0, A(dst), A(tmp), 2)
+                    else:
+                        lib.mmo_multiply_plain(o.p, 0, A(image[ii]), A(filter_pts[m, c]), N, A(dst))
+                        started[i] = True
+            assert all(started), "filter with all zero is not supported"
+        low = np.zeros((self.n_out, 2, 1, N), np.uint64)
+        share = np.zeros(self.out_shape, np.uint64)
+        zero = np.zeros((2, 1, N), np.uint64)
+        m0, m1 = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        lib.mmo_truncate_masks(o.p, A(m0), A(m1))
+        nsh, nsw = lib.mmo_conv_indexer_slices(self.mask_ix, 1), lib.mmo_conv_indexer_slices(self.mask_ix, 2)
+        assert nsh * nsw == self.n_sp
+        q0 = np.uint64(o.q[0])
+        for m in range(self.M):                                          # addRandomMask :761-788
+            cid, hoff = m * self.n_sp, 0
+            for sh in range(nsh):
+                woff = 0
+                for sw in range(nsw):
+                    (th, tw), tg = self.targets(self.mask_ix, sh, sw)
+                    ct = low[cid]
+                    lib.mmo_mod_switch_to_last(o.p, A(out[cid]), A(ct), 2)                 # flood :382
+                    lib.mmo_encrypt_zero_asymmetric(o.p, 1, A(pk1), A(u[cid]), None, A(e1[cid]), A(zero))
+                    lib.mmo_ct_add(o.p, 1, A(ct), A(zero), 2)
+                    r = mask[cid]
+                    gathered = np.ascontiguousarray(r[tg.astype(np.int64)])               # :209-221
+                    coeffs = np.zeros(len(tg), np.uint64)
+                    lib.mmo_decrypt_scale_and_round(o.p, 1, A(gathered), len(tg), A(coeffs))
+                    ct[0, 0] = np.where(ct[0, 0] >= r, ct[0, 0] - r, ct[0, 0] + q0 - r)   # sub_poly_inplace
+                    share[m, hoff:hoff + th, woff:woff + tw] = coeffs.reshape(th, tw)
+                    woff += tw
+                    cid += 1
+                hoff += th
+        low[:, 0] &= m0[0]                                               # truncate_for_decryption
+        low[:, 1] &= m1[0]
+        for m in range(self.M):                                          # removeUnusedCoeffs :828-847
+            cid = m * self.n_sp
+            for sh in range(nsh):
+                for sw in range(nsw):
+                    _, tg = self.targets(self.keep_ix, sh, sw)
+                    keep = np.zeros(N, bool)
+                    keep[tg.astype(np.int64)] = True
+                    low[cid, 0, 0, ~keep] = 0
+                    cid += 1
+        return low, share
+
+    def decrypt(self, sk1, cts):
+        """decryptToTensor :853-941"""
+        o, lib, N = self.o, self.lib, self.o.N
+        out = np.zeros(self.out_shape, np.uint64)
+        pt = np.zeros(N, np.uint64)
+        nsh, nsw = lib.mmo_conv_indexer_slices(self.mask_ix, 1), lib.mmo_conv_indexer_slices(self.mask_ix, 2)
+        for m in range(self.M):
+            cid, hoff = m * self.n_sp, 0
+            for sh in range(nsh):
+                woff = 0
+                for sw in range(nsw):
+                    (th, tw), tg = self.targets(self.mask_ix, sh, sw)
+                    lib.mmo_decrypt(o.p, 1, A(sk1), A(cts[cid]), A(pt))
+                    out[m, hoff:hoff + th, woff:woff + tw] = pt[tg.astype(np.int64)].reshape(th, tw)
+                    woff += tw
+                    cid += 1
+                hoff += th
+        return out
+
+
+def ideal_conv(img, filters, same, stride, t):
+    """Tensor::Conv2D (tensor.h:274-362) on signed representatives, result mod t"""
+    C_, H, W = img.shape
+    M, _, fh, fw = filters.shape
+    ph, pw = ((fh - 1), (fw - 1)) if same else (0, 0)
+    top, left = (ph + 1) // 2, (pw + 1) // 2
+    x = np.zeros((C_, H + ph, W + pw), dtype=object)
+    x[:, top:top + H, left:left + W] = img.astype(object)
+    oh, ow = (H + ph - fh + stride) // stride, (W + pw - fw + stride) // stride
+    out = np.zeros((M, oh, ow), dtype=object)
+    f = filters.astype(object)
+    for r in range(fh):
+        for c in range(fw):
+            patch = x[:, r:r + (oh - 1) * stride + 1:stride, c:c + (ow - 1) * stride + 1:stride]
+            out += np.einsum("mc,chw->mhw", f[:, :, r, c], patch)
+    return out % t

@@ -1,0 +1,116 @@
+"""GPU parity of the HomConv2DSS layer calls (C ABI via the Python mirror) against the
+oracle's reference-shaped flow: encoders, encrypted image, server output ciphertexts, share
+tensor and decrypted tensor, bit for bit on identical randomness."""
+import numpy as np
+import pytest
+
+from tests.layer_fixtures import SEED, keypair, noise, rns_uniform, signed_weights, ternary
+from tests.oracle_binding import OracleCtx, uniform_mod
+from tests.oracle_layers import ConvOracle, ideal_conv
+
+pytestmark = pytest.mark.gpu
+T = 1 << 37
+N = 4096
+CASES = [
+    ((3, 8, 8), (3, 3), 2, 1, 1, True),
+    ((2, 70, 70), (3, 3), 1, 1, 1, True),
+    ((5, 12, 12), (1, 1), 3, 0, 2, True),
+    ((4, 17, 17), (3, 3), 2, 0, 2, True),
+    ((6, 30, 30), (5, 5), 2, 1, 1, True),
+    ((3, 8, 8), (3, 3), 2, 1, 1, False),
+    ((3, 230, 230), (7, 7), 2, 0, 2, False),   # ResNet50 conv1 geometry (Appendix D), 2 filters
+    ((8, 9, 11), (2, 3), 3, 1, 1, True),       # fh != fw: FilterIndexer reads "h" from the width (Appendix B)
+    ((130, 7, 7), (1, 1), 2, 0, 1, True),      # 83 channels per polynomial, ragged last channel slice
+]
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import torch
+    assert torch.cuda.is_available()
+    import openmm_amd
+    return openmm_amd
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", CASES)
+def test_conv_layer_bit_exact(mm, ishape, fhw, M, same, stride, shared):
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
+    fshape = (ishape[0],) + tuple(fhw)
+    cv = ConvOracle(o, ishape, fshape, M, same, stride, shared)
+    meta = Meta(ishape, fshape, M, same, stride, shared)
+    sk, pk = keypair(o)
+    client, server = HomConv2DSS(), HomConv2DSS()
+    client.setUp(g, sk_ntt=dev(sk))
+    server.setUp(g, pk_ntt=dev(pk))
+    plan = server.plan(meta)
+    assert (plan.n_in, plan.n_cslices, plan.n_spatial, plan.n_out) == (cv.n_in, cv.n_cs, cv.n_sp, cv.n_out)
+    assert plan.out_shape == cv.out_shape and plan.slice_strides == cv.slice_strides
+
+    img = uniform_mod(SEED + 20, ishape, T)
+    share0 = uniform_mod(SEED + 21, ishape, T)
+    share1 = (img - share0) & np.uint64(T - 1)
+    filters = signed_weights(SEED + 22, (M,) + fshape, 1 << 12, T)
+    a, e = rns_uniform(o, SEED + 30, cv.n_in, 2), noise(SEED + 31, (cv.n_in, N))
+    client_in = share0 if shared else img
+    # client: encryptImage
+    ref_cts = cv.encrypt_image(sk, client_in, a, e)
+    got_cts = client.encryptImage(dev(client_in), meta, (dev(a), dev(e)))
+    assert np.array_equal(host(got_cts), ref_cts)
+    # server: encoders
+    ref_f = cv.encode_filters(filters)
+    got_f = server.encodeFilters(dev(filters), meta)
+    assert np.array_equal(host(got_f), ref_f)
+    ref_s = got_s = None
+    if shared:
+        ref_s = cv.encode_image(share1)
+        got_s = server.encodeImage(dev(share1), meta)
+        assert np.array_equal(host(got_s), ref_s)
+    # server: conv2DSS
+    u, e1 = ternary(SEED + 40, (cv.n_out, N)), noise(SEED + 41, (cv.n_out, N))
+    mask = rns_uniform(o, SEED + 50, cv.n_out, 1)[:, 0]
+    ref_out, ref_share = cv.server(ref_cts, ref_s, ref_f, np.ascontiguousarray(pk[:, :1]), u, e1, mask)
+    got_out, got_share = server.conv2DSS(got_cts, got_s, got_f, meta, (dev(u), dev(e1), dev(mask)))
+    assert np.array_equal(host(got_out), ref_out)
+    assert np.array_equal(host(got_share), ref_share)
+    # client: decryptToTensor, then the reference's acceptance identity
+    ref_dec = cv.decrypt(np.ascontiguousarray(sk[:1]), ref_out)
+    got_dec = host(client.decryptToTensor(got_out, meta))
+    assert np.array_equal(got_dec, ref_dec)
+    ideal = ideal_conv(img, filters, same, stride, T)
+    diff = (got_dec.astype(object) + host(got_share).astype(object) - ideal) % T
+    assert all(d in (0, 1, T - 1) for d in diff.ravel())
+    if not (stride > 1 and fhw == (1, 1)):
+        ideal_gpu = host(server.idealFunctionality(dev(img), dev(filters), meta))
+        assert np.array_equal(ideal_gpu.astype(object), ideal)
+
+
+def test_conv_errors(mm):
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    import torch
+    g = mm.Context(N, (60, 49), T)
+    h = HomConv2DSS()
+    h.setUp(g)
+    with pytest.raises(mm.MMHError) as ei:   # filter larger than the polynomial
+        h.plan(Meta((1, 100, 100), (1, 70, 70), 1, 0, 1))
+    assert ei.value.code == 7
+    with pytest.raises(mm.MMHError) as ei:   # fh > fw: FilterIndexer yields a negative index, the
+        h.plan(Meta((8, 9, 11), (8, 3, 2), 3, 1, 1))   # reference LOG(FATAL)s in Encode (tensor_encoder.cc:268-270)
+    assert ei.value.code == 6
+    meta = Meta((3, 8, 8), (3, 3, 3), 2, 1, 1)
+    with pytest.raises(mm.MMHError) as ei:   # image shape mismatch -> ERR_DIM_MISMATCH
+        h.encodeImage(torch.zeros((3, 8, 9), dtype=torch.int64, device="cuda"), meta)
+    assert ei.value.code == 3
+    with pytest.raises(mm.MMHError) as ei:   # no public key -> ERR_CONFIG
+        h.conv2DSS(None, None, None, meta, None)
+    assert ei.value.code == 1
