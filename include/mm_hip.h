@@ -223,6 +223,62 @@ int mmh_conv_decrypt(const mmh_conv_plan *plan, const uint64_t *d_sk_ntt, const 
                      uint64_t *d_out, void *stream);
 
 /* =====================================================================================
+ * HomFCSS (include/gemini/cheetah/hom_fc_ss.h:27-121): out = W * in for a rows x cols weight
+ * matrix (row-major) and a length-cols input vector, Meta {weight_shape, input_shape,
+ * is_shared_input}.
+ * ===================================================================================== */
+typedef struct mmh_fc_meta {
+  int64_t rows, cols;       /* meta.weight_shape; meta.input_shape = cols */
+  int32_t is_shared_input;
+} mmh_fc_meta;
+typedef struct mmh_fc_plan mmh_fc_plan;
+int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan **out);
+int mmh_fc_plan_destroy(mmh_fc_plan *plan);
+/* split = getSplit's (d0, d1) (hom_fc_ss.cc:25-50); n_in = ceil(cols/d1), n_out = ceil(rows/d0) */
+int mmh_fc_plan_info(const mmh_fc_plan *plan, int64_t split[2], size_t *n_in_cts, size_t *n_out_cts);
+/* HomFCSS::encodeInputVector (hom_fc_ss.cc:275-325): -> [n_in][N] */
+int mmh_fc_encode_input(const mmh_fc_plan *plan, const uint64_t *d_vec, uint64_t *d_pts, void *stream);
+/* HomFCSS::encodeWeightMatrix (hom_fc_ss.cc:327-392): -> [n_out][n_in][N] */
+int mmh_fc_encode_weights(const mmh_fc_plan *plan, const uint64_t *d_w, uint64_t *d_pts, void *stream);
+/* HomFCSS::encryptInputVector (hom_fc_ss.cc:214-273) with injected randomness */
+int mmh_fc_encrypt_input(const mmh_fc_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_vec,
+                         const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream);
+/* HomFCSS::matVecMul (hom_fc_ss.cc:394-471), USE_APPROX_RESHARE build; arguments as mmh_conv_server,
+ * randomness per output row block [n_out][N]; d_out_share has `rows` entries */
+int mmh_fc_server(const mmh_fc_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                  const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                  const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
+                  void *stream);
+/* HomFCSS::decryptToVector (hom_fc_ss.cc:572-602) */
+int mmh_fc_decrypt(const mmh_fc_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_cts, uint64_t *d_out,
+                   void *stream);
+
+/* =====================================================================================
+ * HomBNSS, SIMD path = BOLE (include/gemini/cheetah/hom_bn_ss.h:25-198; hom_bn_ss.cc:151-406).
+ * The context's plain modulus must be a batching prime (setUp_Field, hom_bn_ss.cc:122-126).
+ * A length-n vector occupies n_ct = ceil(n / min(n, N)) ciphertexts of N slots each.
+ * ===================================================================================== */
+/* HomBNSS::encodeVector / encodeScales (hom_bn_ss.cc:203-239): -> [n_ct][N] */
+int mmh_bn_encode_vector(const mmh_ctx *ctx, const uint64_t *d_vec, size_t n, uint64_t *d_pts, void *stream);
+/* HomBNSS::encryptVector (hom_bn_ss.cc:151-189) with injected randomness a [n_ct][L][N], e [n_ct][N] */
+int mmh_bn_encrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_vec, size_t n,
+                          const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream);
+/* HomBNSS::bn (hom_bn_ss.cc:241-278) + addMask (:318-362): (cts [+ share_pts]) * scale_pts, mod-switch,
+ * + encode(r), truncate.  d_random: n raw 64-bit words (r = word % p, :332-334); share = -r mod p.
+ * d_share_pts NULL when !is_shared_input. */
+int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                  const uint64_t *d_scale_pts, size_t n, const uint64_t *d_random, uint64_t *d_out_cts,
+                  uint64_t *d_out_share, void *stream);
+/* HomBNSS::bole (hom_bn_ss.cc:280-316) + addMask: out[i] = ex[i]*py[i] + ey[i]*px[i].
+ * d_enc_xy = [ex ; ey] (2*n_ct ciphertexts), d_pts_yx = [py ; px] (2*n_ct plaintexts).
+ * The reference destroys ex/ey in place (:304-305); here the inputs are left untouched. */
+int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, const uint64_t *d_pts_yx, size_t n,
+                    const uint64_t *d_random, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream);
+/* HomBNSS::decryptToVector (hom_bn_ss.cc:364-406): last-level cts -> n values */
+int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n,
+                          uint64_t *d_out, void *stream);
+
+/* =====================================================================================
  * Modulus conversion: local share arithmetic of SCI's Truncation class
  * (SCI/src/BuildingBlocks/truncation.h:29-210), split around its single COT call.
  * party: 1 = ALICE (the COT sender, truncation.cpp:549,607,665,351,412), 2 = BOB.

@@ -101,6 +101,27 @@ __global__ __launch_bounds__(256) void gather_targets_kernel(const u64 *__restri
   out[m * plane + dst[g]] = pts[((m * n_spatial + slice[g]) << logN) + coef[g]];
 }
 
+int launch_share_from_mask(const mmh_ctx *ctx, const u64 *r, u64 *out, size_t groups, size_t n_targets,
+                           size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
+                           hipStream_t s) {
+  const size_t total = groups * n_targets;
+  if (!total) return MMH_OK;
+  hipLaunchKernelGGL(share_from_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r, out, groups,
+                     n_targets, n_spatial, plane, ctx->logN, coef, dst, slice, ctx->bfv, ctx->d_mods);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t groups, size_t n_targets,
+                          size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
+                          hipStream_t s) {
+  const size_t total = groups * n_targets;
+  if (!total) return MMH_OK;
+  hipLaunchKernelGGL(gather_targets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pts, out, groups,
+                     n_targets, n_spatial, plane, ctx->logN, coef, dst, slice);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
 template <class T>
 static int upload_vec(mmh_conv_plan *p, const std::vector<T> &v, T **d) {
   MMH_HIP(hipMalloc((void **)d, std::max<size_t>(1, v.size()) * sizeof(T)));
@@ -316,13 +337,9 @@ extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts,
   if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
   // ... sample_random_mask (approximate re-sharing) + sub_poly_inplace, share scattered into the tensor
   if (!rc) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
-  if (!rc) {
-    const size_t total = M * p->n_targets;
-    hipLaunchKernelGGL(share_from_mask_kernel, dim3(nblk(total)), dim3(256), 0, s, d_mask, d_out_share, M,
-                       p->n_targets, S, (size_t)(p->out_h * p->out_w), ctx->logN, p->d_tgt_coef, p->d_tgt_dst,
-                       p->d_tgt_slice, ctx->bfv, ctx->d_mods);
-    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
-  }
+  if (!rc)
+    rc = launch_share_from_mask(ctx, d_mask, d_out_share, M, p->n_targets, S, (size_t)(p->out_h * p->out_w),
+                                p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
   // truncate_for_decryption :698-703 and removeUnusedCoeffs :800-851 in one pass
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, S, stream);
   cleanup();
@@ -337,13 +354,9 @@ extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt
   void *pts = nullptr;
   MMH_HIP(hipMallocAsync(&pts, (p->n_out << ctx->logN) * 8, s));
   int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, p->n_out, (u64 *)pts, stream);
-  if (!rc) {
-    const size_t M = (size_t)p->meta.n_filters, total = M * p->n_targets;
-    hipLaunchKernelGGL(gather_targets_kernel, dim3(nblk(total)), dim3(256), 0, s, (const u64 *)pts, d_out, M,
-                       p->n_targets, p->n_spatial, (size_t)(p->out_h * p->out_w), ctx->logN, p->d_tgt_coef,
-                       p->d_tgt_dst, p->d_tgt_slice);
-    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
-  }
+  if (!rc)
+    rc = launch_gather_targets(ctx, (const u64 *)pts, d_out, (size_t)p->meta.n_filters, p->n_targets, p->n_spatial,
+                               (size_t)(p->out_h * p->out_w), p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
   (void)hipFreeAsync(pts, s);
   return rc;
 }

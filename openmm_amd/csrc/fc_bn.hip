@@ -1,0 +1,381 @@
+// HomFCSS (include/gemini/cheetah/hom_fc_ss.cc) and the SIMD half of HomBNSS
+// (hom_bn_ss.cc:151-406: encryptVector / encodeVector / bn / bole / addMask /
+// decryptToVector) as layer-level calls built from the batched kernels.
+#include "bfv_device.hpp"
+#include "common.hpp"
+#include "geometry.hpp"
+
+namespace mmh {
+int launch_share_from_mask(const mmh_ctx *ctx, const u64 *r, u64 *out, size_t groups, size_t n_targets,
+                           size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
+                           hipStream_t s);
+int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t groups, size_t n_targets,
+                          size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
+                          hipStream_t s);
+}  // namespace mmh
+
+struct mmh_fc_plan {
+  const mmh_ctx *ctx = nullptr;
+  mmh_fc_meta meta{};
+  long d0 = 0, d1 = 0;         // getSplit: rows x cols of one weight block
+  size_t n_in = 0, n_out = 0;  // input chunks, output row blocks
+  size_t n_targets = 0;
+  uint32_t *d_tgt_coef = nullptr, *d_tgt_dst = nullptr, *d_tgt_slice = nullptr;
+  uint8_t *d_keep = nullptr;   // [n_out][N]
+  std::vector<void *> allocs;
+};
+
+namespace mmh {
+__device__ __forceinline__ u64 red_t2(u64 v, const ModC &t) { return barrett128(0, v, t.q, t.barrett_hi, t.barrett_lo); }
+
+// encodeInputVector / encryptInputVector (hom_fc_ss.cc:296-318, :239-252): chunk i as
+// v0 - sum_{j>=1} v_j X^{N-j}; coefficient N-len of a shorter last chunk keeps what the previous
+// chunk left in the reference's reused buffer, reproduced here.
+__global__ __launch_bounds__(256) void fc_encode_input_kernel(const u64 *__restrict__ vec, u64 *__restrict__ polys,
+                                                              size_t n_in, long len_total, long d1, int logN,
+                                                              ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_in << logN)) return;
+  const long N = 1L << logN, i = (long)(idx >> logN), j = (long)(idx & (N - 1));
+  const long start = i * d1, len = (start + d1 <= len_total ? d1 : len_total - start);
+  u64 v = 0;
+  if (j == 0) {
+    v = vec[start];
+  } else {
+    const long jj = N - j;  // this coefficient holds -v[start + jj]
+    long src = -1;
+    if (jj < len) src = start + jj;
+    else if (jj == len && i > 0 && len < d1) src = start - d1 + jj;  // stale entry of chunk i-1
+    if (src >= 0) {
+      const u64 u = vec[src];
+      v = u > 0 ? t.q - u : 0;
+    }
+  }
+  polys[idx] = red_t2(v, t);
+}
+
+// encodeWeightMatrix (hom_fc_ss.cc:346-385): block (rb, cb), entry (r, c) at coefficient r*d1 + c
+__global__ __launch_bounds__(256) void fc_encode_weights_kernel(const u64 *__restrict__ W, u64 *__restrict__ polys,
+                                                                size_t n_polys, long rows, long cols, long d0,
+                                                                long d1, long n_cb, int logN, ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_polys << logN)) return;
+  const long N = 1L << logN, k = (long)(idx >> logN), j = (long)(idx & (N - 1));
+  const long rb = k / n_cb, cb = k % n_cb, r = j / d1, c = j % d1;
+  const long row = rb * d0 + r, col = cb * d1 + c;
+  u64 v = 0;
+  if (r < d0 && row < rows && col < cols) v = red_t2(W[row * cols + col], t);
+  polys[idx] = v;
+}
+
+// HomBNSS chunking (hom_bn_ss.cc:171-178): chunk k of a length-n vector, zero padded to N slots
+__global__ __launch_bounds__(256) void chunk_pad_kernel(const u64 *__restrict__ vec, u64 *__restrict__ slots,
+                                                        size_t n_ct, size_t n, size_t sub_len, int logN) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_ct << logN)) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const size_t src = k * sub_len + i;
+  slots[idx] = (i < sub_len && src < n) ? vec[src] : 0;
+}
+__global__ __launch_bounds__(256) void chunk_unpad_kernel(const u64 *__restrict__ slots, u64 *__restrict__ vec,
+                                                          size_t n, size_t sub_len, int logN) {
+  const size_t src = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (src >= n) return;
+  vec[src] = slots[((src / sub_len) << logN) + src % sub_len];
+}
+// addMask (hom_bn_ss.cc:333-340): r = random % p in place, share = -r mod p
+__global__ __launch_bounds__(256) void bn_mask_kernel(const u64 *__restrict__ random, u64 *__restrict__ r,
+                                                      u64 *__restrict__ share, size_t n, ModC t) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 v = red_t2(random[i], t);
+  r[i] = v;
+  share[i] = v ? t.q - v : 0;
+}
+
+template <class P, class T>
+static int upload_vec(P *p, const std::vector<T> &v, T **d) {
+  MMH_HIP(hipMalloc((void **)d, std::max<size_t>(1, v.size()) * sizeof(T)));
+  p->allocs.push_back(*d);
+  if (!v.empty()) MMH_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return MMH_OK;
+}
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+}  // namespace mmh
+
+using namespace mmh;
+#define CHECK_RC(x)      \
+  do {                   \
+    int rc_ = (x);       \
+    if (rc_) return rc_; \
+  } while (0)
+#define KLAUNCH(kern, total, s, ...)                                                     \
+  do {                                                                                   \
+    if ((total) > 0) {                                                                   \
+      hipLaunchKernelGGL(kern, dim3(nblk(total)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__); \
+      MMH_HIP(hipGetLastError());                                                        \
+    }                                                                                    \
+  } while (0)
+
+// ------------------------------------------------------------------------------ HomFCSS
+extern "C" int mmh_fc_plan_destroy(mmh_fc_plan *p) {
+  if (!p) return MMH_OK;
+  for (void *a : p->allocs) (void)hipFree(a);
+  delete p;
+  return MMH_OK;
+}
+
+extern "C" int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan **out) {
+  MMH_REQUIRE(ctx && meta && out, MMH_ERR_NULL_POINTER);
+  *out = nullptr;
+  MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
+  MMH_REQUIRE(meta->rows > 0 && meta->cols > 0, MMH_ERR_INVALID_ARG);
+  mmh_fc_plan *p = new mmh_fc_plan();
+  p->ctx = ctx;
+  p->meta = *meta;
+  const long N = (long)ctx->N;
+  fc_split(meta->rows, meta->cols, N, p->d0, p->d1);
+  p->n_in = (size_t)((meta->cols + p->d1 - 1) / p->d1);
+  p->n_out = (size_t)((meta->rows + p->d0 - 1) / p->d0);
+  // addRandomMask targets i*d1 (hom_fc_ss.cc:482-485, :504-510); removeUnusedCoeffs keeps
+  // index < rows_in_block*d1 with index % d1 == 0 (:543-548); decryptToVector reads the same (:595-598)
+  std::vector<u32> coef, dst, slice;
+  std::vector<uint8_t> keep(p->n_out * (size_t)N, 0);
+  for (size_t b = 0; b < p->n_out; ++b) {
+    const long r0 = (long)b * p->d0, r1 = std::min<long>(r0 + p->d0, meta->rows);
+    for (long r = r0; r < r1; ++r) {
+      coef.push_back((u32)((r - r0) * p->d1));
+      dst.push_back((u32)r);
+      slice.push_back((u32)b);
+      keep[b * N + (r - r0) * p->d1] = 1;
+    }
+  }
+  p->n_targets = coef.size();
+  int rc;
+  if ((rc = upload_vec(p, coef, &p->d_tgt_coef)) || (rc = upload_vec(p, dst, &p->d_tgt_dst)) ||
+      (rc = upload_vec(p, slice, &p->d_tgt_slice)) || (rc = upload_vec(p, keep, &p->d_keep))) {
+    mmh_fc_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return MMH_OK;
+}
+
+extern "C" int mmh_fc_plan_info(const mmh_fc_plan *p, int64_t split[2], size_t *n_in_cts, size_t *n_out_cts) {
+  MMH_REQUIRE(p, MMH_ERR_NULL_POINTER);
+  if (split) split[0] = p->d0, split[1] = p->d1;
+  if (n_in_cts) *n_in_cts = p->n_in;
+  if (n_out_cts) *n_out_cts = p->n_out;
+  return MMH_OK;
+}
+
+extern "C" int mmh_fc_encode_input(const mmh_fc_plan *p, const uint64_t *d_vec, uint64_t *d_pts, void *stream) {
+  MMH_REQUIRE(p && d_vec && d_pts, MMH_ERR_NULL_POINTER);
+  KLAUNCH(fc_encode_input_kernel, p->n_in << p->ctx->logN, stream, d_vec, d_pts, p->n_in, (long)p->meta.cols, p->d1,
+          p->ctx->logN, p->ctx->bfv.t);
+  return MMH_OK;
+}
+
+extern "C" int mmh_fc_encode_weights(const mmh_fc_plan *p, const uint64_t *d_w, uint64_t *d_pts, void *stream) {
+  MMH_REQUIRE(p && d_w && d_pts, MMH_ERR_NULL_POINTER);
+  const size_t n_polys = p->n_in * p->n_out;
+  KLAUNCH(fc_encode_weights_kernel, n_polys << p->ctx->logN, stream, d_w, d_pts, n_polys, (long)p->meta.rows,
+          (long)p->meta.cols, p->d0, p->d1, (long)p->n_in, p->ctx->logN, p->ctx->bfv.t);
+  return MMH_OK;
+}
+
+extern "C" int mmh_fc_encrypt_input(const mmh_fc_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_vec,
+                                    const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  MMH_REQUIRE(p && d_sk_ntt && d_vec && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (p->n_in << p->ctx->logN) * 8, s));
+  int rc = mmh_fc_encode_input(p, d_vec, (u64 *)pts, stream);
+  if (!rc) rc = mmh_encrypt_symmetric(p->ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, p->n_in, d_cts, stream);
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}
+
+extern "C" int mmh_fc_server(const mmh_fc_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                             const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                             uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(p && d_in_cts && d_weight_pts && d_pk_ntt_last && d_u && d_e1 && d_mask && d_out_cts && d_out_share,
+              MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);  // matVecMul :424-426
+  const mmh_ctx *ctx = p->ctx;
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = ctx->N;
+  void *input = nullptr, *acc = nullptr, *zero = nullptr;
+  int rc = MMH_OK;
+  const u64 *cts = d_in_cts;
+  if (p->meta.is_shared_input) {  // :431-440
+    MMH_HIP(hipMallocAsync(&input, p->n_in * 4 * N * 8, s));
+    rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)input, stream);
+    cts = (const u64 *)input;
+  }
+  if (!rc && hipMallocAsync(&acc, p->n_out * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && hipMallocAsync(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  // :443-457: out[j] = sum_i input[i] * matrix[j][i]
+  if (!rc)
+    rc = mmh_mul_plain_acc(ctx, 0, cts, p->n_in, d_weight_pts, p->n_out * p->n_in, p->n_out, 1, p->n_in, 1, 0,
+                           p->n_in, 1, 0, (u64 *)acc, stream);
+  // addRandomMask :487-517 (the output vector is sized once, not per worker as the reference does)
+  if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
+  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, nullptr, d_e1, p->n_out, (u64 *)zero, stream);
+  if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
+  if (!rc) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
+  if (!rc)
+    rc = launch_share_from_mask(ctx, d_mask, d_out_share, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
+                                p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  // truncate_for_decryption :462-466 + removeUnusedCoeffs :525-561
+  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, p->n_out, stream);
+  if (input) (void)hipFreeAsync(input, s);
+  if (acc) (void)hipFreeAsync(acc, s);
+  if (zero) (void)hipFreeAsync(zero, s);
+  return rc;
+}
+
+extern "C" int mmh_fc_decrypt(const mmh_fc_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
+                              uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(p && d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
+  const mmh_ctx *ctx = p->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (p->n_out << ctx->logN) * 8, s));
+  int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, p->n_out, (u64 *)pts, stream);
+  if (!rc)
+    rc = launch_gather_targets(ctx, (const u64 *)pts, d_out, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
+                               p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}
+
+// ------------------------------------------------------------------- HomBNSS, SIMD path
+static int bn_counts(const mmh_ctx *ctx, size_t n, size_t *sub_len, size_t *n_ct) {
+  MMH_REQUIRE(ctx, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(ctx->batching, MMH_ERR_INVALID_ARG);  // setUp_Field: "invalid SIMD modulus"
+  MMH_REQUIRE(n > 0, MMH_ERR_INVALID_ARG);
+  *sub_len = std::min(n, ctx->N);
+  *n_ct = (n + *sub_len - 1) / *sub_len;
+  return MMH_OK;
+}
+
+extern "C" int mmh_bn_encode_vector(const mmh_ctx *ctx, const uint64_t *d_vec, size_t n, uint64_t *d_pts,
+                                    void *stream) {
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_vec && d_pts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *slots = nullptr;
+  MMH_HIP(hipMallocAsync(&slots, (n_ct << ctx->logN) * 8, s));
+  int rc = MMH_OK;
+  hipLaunchKernelGGL(chunk_pad_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, d_vec, (u64 *)slots, n_ct, n,
+                     sub, ctx->logN);
+  if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  if (!rc) rc = mmh_batch_encode(ctx, (const u64 *)slots, n_ct, d_pts, stream);
+  (void)hipFreeAsync(slots, s);
+  return rc;
+}
+
+extern "C" int mmh_bn_encrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_vec, size_t n,
+                                     const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_sk_ntt && d_vec && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (n_ct << ctx->logN) * 8, s));
+  int rc = mmh_bn_encode_vector(ctx, d_vec, n, (u64 *)pts, stream);
+  if (!rc) rc = mmh_encrypt_symmetric(ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, n_ct, d_cts, stream);
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}
+
+// shared tail of bn / bole: mod-switch, addMask, truncate
+static int bn_tail(const mmh_ctx *ctx, const u64 *acc, size_t n, size_t n_ct, size_t sub, const u64 *d_random,
+                   u64 *d_out_cts, u64 *d_out_share, hipStream_t s) {
+  void *r = nullptr, *rpts = nullptr;
+  int rc = mmh_mod_switch_to_last(ctx, acc, n_ct, d_out_cts, s);
+  if (!rc && hipMallocAsync(&r, n * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && hipMallocAsync(&rpts, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc) {
+    hipLaunchKernelGGL(bn_mask_kernel, dim3(nblk(n)), dim3(256), 0, s, d_random, (u64 *)r, d_out_share, n,
+                       ctx->bfv.t);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  if (!rc) rc = mmh_bn_encode_vector(ctx, (const u64 *)r, n, (u64 *)rpts, s);
+  if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)rpts, n_ct, 0, d_out_cts, s);
+  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, n_ct, nullptr, 1, s);
+  if (r) (void)hipFreeAsync(r, s);
+  if (rpts) (void)hipFreeAsync(rpts, s);
+  (void)sub;
+  return rc;
+}
+
+extern "C" int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                             const uint64_t *d_scale_pts, size_t n, const uint64_t *d_random, uint64_t *d_out_cts,
+                             uint64_t *d_out_share, void *stream) {
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_in_cts && d_scale_pts && d_random && d_out_cts && d_out_share, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = ctx->N;
+  void *sum = nullptr, *acc = nullptr;
+  int rc = MMH_OK;
+  const u64 *cts = d_in_cts;
+  if (d_share_pts) {  // hom_bn_ss.cc:263-265
+    MMH_HIP(hipMallocAsync(&sum, n_ct * 4 * N * 8, s));
+    rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, n_ct, 0, (u64 *)sum, stream);
+    cts = (const u64 *)sum;
+  }
+  if (!rc && hipMallocAsync(&acc, n_ct * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  // :265-267: out[i] = cts[i] * scales[i]
+  if (!rc) rc = mmh_mul_plain_acc(ctx, 0, cts, n_ct, d_scale_pts, n_ct, 1, n_ct, 1, 0, 1, 0, 0, 1, (u64 *)acc, stream);
+  if (!rc) rc = bn_tail(ctx, (const u64 *)acc, n, n_ct, sub, d_random, d_out_cts, d_out_share, s);
+  if (sum) (void)hipFreeAsync(sum, s);
+  if (acc) (void)hipFreeAsync(acc, s);
+  return rc;
+}
+
+extern "C" int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, const uint64_t *d_pts_yx, size_t n,
+                               const uint64_t *d_random, uint64_t *d_out_cts, uint64_t *d_out_share,
+                               void *stream) {
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_enc_xy && d_pts_yx && d_random && d_out_cts && d_out_share, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  hipStream_t s = (hipStream_t)stream;
+  void *acc = nullptr;
+  MMH_HIP(hipMallocAsync(&acc, n_ct * 4 * ctx->N * 8, s));
+  // hom_bn_ss.cc:304-306: out[i] = ex[i]*py[i] + ey[i]*px[i]; operands are [ex; ey] and [py; px]
+  int rc = mmh_mul_plain_acc(ctx, 0, d_enc_xy, 2 * n_ct, d_pts_yx, 2 * n_ct, 1, n_ct, 2, n_ct, 1, 0, n_ct, 1,
+                             (u64 *)acc, stream);
+  if (!rc) rc = bn_tail(ctx, (const u64 *)acc, n, n_ct, sub, d_random, d_out_cts, d_out_share, s);
+  (void)hipFreeAsync(acc, s);
+  return rc;
+}
+
+extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n,
+                                     uint64_t *d_out, void *stream) {
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr, *slots = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (n_ct << ctx->logN) * 8, s));
+  int rc = MMH_OK;
+  if (hipMallocAsync(&slots, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc) rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, n_ct, (u64 *)pts, stream);  // hom_bn_ss.cc:389
+  if (!rc) rc = mmh_batch_decode(ctx, (const u64 *)pts, n_ct, (u64 *)slots, stream);
+  if (!rc) {
+    hipLaunchKernelGGL(chunk_unpad_kernel, dim3(nblk(n)), dim3(256), 0, s, (const u64 *)slots, d_out, n, sub,
+                       ctx->logN);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  (void)hipFreeAsync(pts, s);
+  if (slots) (void)hipFreeAsync(slots, s);
+  return rc;
+}

@@ -1,0 +1,93 @@
+"""Host-side mirror of ``gemini::HomBNSS``, SIMD path = BOLE
+(include/gemini/cheetah/hom_bn_ss.h:25-198, hom_bn_ss.cc:151-406)."""
+from dataclasses import dataclass
+
+from . import lib as L
+
+
+@dataclass
+class Meta:
+    """HomBNSS::Meta fields used by the SIMD path"""
+    vec_shape: tuple           # (n,)
+    target_base_mod: int       # must equal the context's plain modulus (hom_bn_ss.cc:156)
+    is_shared_input: bool = True
+
+
+class HomBNSS:
+    def __init__(self):
+        self.ctx = self.sk_ntt = self.pk_ntt = None
+
+    # setUp_Field (hom_bn_ss.cc:107-149)
+    def setUp_Field(self, target_field_mod, ctx, sk_ntt=None, pk_ntt=None):
+        if ctx.t != target_field_mod:
+            raise L.MMHError(7, "HomBNSS: invalid target field mod this SEALContext")
+        self.ctx, self.sk_ntt, self.pk_ntt = ctx, sk_ntt, pk_ntt
+        self.sk_last = None if sk_ntt is None else sk_ntt[:1].contiguous()
+        return 0
+
+    def _need(self, cond, code, what):
+        if not cond:
+            raise L.MMHError(code, what)
+
+    def _n_ct(self, meta):
+        n = meta.vec_shape[0]
+        sub = min(n, self.ctx.N)
+        return n, (n + sub - 1) // sub
+
+    def _check(self, meta):
+        self._need(self.ctx is not None, 1, "HomBNSS: not set up")
+        self._need(meta.target_base_mod == self.ctx.t, 6, "HomBNSS: target_base_mod")  # ERR_OUT_BOUND
+
+    def encryptVector(self, vec, meta, rand):  # :151-189
+        self._check(meta)
+        self._need(self.sk_ntt is not None, 1, "encryptVector: no secret key")
+        n, n_ct = self._n_ct(meta)
+        a, e = rand
+        out = self.ctx._empty(n_ct, 2, self.ctx.L, self.ctx.N)
+        L.check(self.ctx.lib.mmh_bn_encrypt_vector(self.ctx.handle, L.dptr(self.sk_ntt), L.dptr(vec), n, L.dptr(a),
+                                                   L.dptr(e), L.dptr(out), L._stream_ptr()))
+        return out
+
+    def encodeVector(self, vec, meta):  # :203-233
+        self._check(meta)
+        n, n_ct = self._n_ct(meta)
+        out = self.ctx._empty(n_ct, self.ctx.N)
+        L.check(self.ctx.lib.mmh_bn_encode_vector(self.ctx.handle, L.dptr(vec), n, L.dptr(out), L._stream_ptr()))
+        return out
+
+    encodeScales = encodeVector  # :235-239
+
+    def bn(self, vec_share0, vec_share1, scales, meta, random):  # :241-278
+        self._check(meta)
+        n, n_ct = self._n_ct(meta)
+        self._need(vec_share0.shape[0] == n_ct and scales.shape[0] == n_ct, 7, "bn: #ciphertexts")
+        if meta.is_shared_input:
+            self._need(vec_share1 is not None and vec_share1.shape[0] == n_ct, 7, "bn: #shares")
+        out_cts, out_share = self.ctx._empty(n_ct, 2, 1, self.ctx.N), self.ctx._empty(n)
+        L.check(self.ctx.lib.mmh_bn_server(self.ctx.handle, L.dptr(vec_share0),
+                                           L.dptr(vec_share1 if meta.is_shared_input else None), L.dptr(scales), n,
+                                           L.dptr(random), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        return out_cts, out_share
+
+    def bole(self, encrypted_x, encrypted_y, encoded_x, encoded_y, meta, random):  # :280-316
+        import torch
+        self._check(meta)
+        n, n_ct = self._n_ct(meta)
+        for v in (encrypted_x, encrypted_y, encoded_x, encoded_y):
+            self._need(v.shape[0] == n_ct, 7, "bole: #ciphertexts")
+        enc = torch.cat([encrypted_x, encrypted_y]).contiguous()
+        pts = torch.cat([encoded_y, encoded_x]).contiguous()
+        out_cts, out_share = self.ctx._empty(n_ct, 2, 1, self.ctx.N), self.ctx._empty(n)
+        L.check(self.ctx.lib.mmh_bole_server(self.ctx.handle, L.dptr(enc), L.dptr(pts), n, L.dptr(random),
+                                             L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        return out_cts, out_share
+
+    def decryptToVector(self, in_vec, meta):  # :364-406
+        self._check(meta)
+        self._need(self.sk_ntt is not None, 1, "decryptToVector: no secret key")
+        n, n_ct = self._n_ct(meta)
+        self._need(in_vec.shape[0] == n_ct, 7, "decryptToVector: #ciphertexts")
+        out = self.ctx._empty(n)
+        L.check(self.ctx.lib.mmh_bn_decrypt_vector(self.ctx.handle, L.dptr(self.sk_last), L.dptr(in_vec), n,
+                                                   L.dptr(out), L._stream_ptr()))
+        return out

@@ -66,6 +66,19 @@ SIGNATURES = {
     "mmh_conv_encrypt_image": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
+    "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],
+    "mmh_fc_plan_destroy": [_vp],
+    "mmh_fc_plan_info": [_vp, C.POINTER(C.c_int64), C.POINTER(_sz), C.POINTER(_sz)],
+    "mmh_fc_encode_input": [_vp, _vp, _vp, _vp],
+    "mmh_fc_encode_weights": [_vp, _vp, _vp, _vp],
+    "mmh_fc_encrypt_input": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_fc_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_fc_decrypt": [_vp, _vp, _vp, _vp, _vp],
+    "mmh_bn_encode_vector": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_bn_encrypt_vector": [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp],
+    "mmh_bn_server": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp],
+    "mmh_bole_server": [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp],
+    "mmh_bn_decrypt_vector": [_vp, _vp, _vp, _sz, _vp, _vp],
     "mmh_r2f_pre": [_int, _vp, _sz, _int, _u64, _vp, _vp, _vp, _vp],
     "mmh_r2f_post": [_int, _vp, _vp, _vp, _sz, _int, _u64, _vp, _vp],
     "mmh_f2r_pre": [_int, _vp, _sz, _u64, _int, _vp, _vp, _vp, _vp],

@@ -200,3 +200,157 @@ def ideal_conv(img, filters, same, stride, t):
             patch = x[:, r:r + (oh - 1) * stride + 1:stride, c:c + (ow - 1) * stride + 1:stride]
             out += np.einsum("mc,chw->mhw", f[:, :, r, c], patch)
     return out % t
+
+
+class FcOracle:
+    """HomFCSS flow (hom_fc_ss.cc) on the oracle context."""
+
+    def __init__(self, o, rows, cols, shared):
+        self.o, self.lib, self.rows, self.cols, self.shared = o, load(), rows, cols, shared
+        setup_geom(self.lib)
+        sp = (C.c_long * 2)()
+        self.lib.mmo_fc_split(rows, cols, o.N, sp)
+        self.d0, self.d1 = sp[0], sp[1]
+        self.n_in, self.n_out = -(-cols // self.d1), -(-rows // self.d0)
+
+    def encode_input(self, vec):
+        out = np.zeros((self.n_in, self.o.N), np.uint64)
+        v = np.ascontiguousarray(vec, np.uint64)
+        assert self.lib.mmo_fc_encode_input(self.o.N, self.o.t, A(v), self.cols, self.d1, A(out)) == self.n_in
+        return out
+
+    def encode_weights(self, W):
+        out = np.zeros((self.n_out, self.n_in, self.o.N), np.uint64)
+        w = np.ascontiguousarray(W, np.uint64)
+        n = self.lib.mmo_fc_encode_weights(self.o.N, self.o.t, A(w), self.rows, self.cols, self.d0, self.d1, A(out))
+        assert n == self.n_in * self.n_out
+        return out
+
+    def encrypt_input(self, sk, vec, a, e):
+        pts = self.encode_input(vec)
+        cts = np.zeros((self.n_in, 2, self.o.L, self.o.N), np.uint64)
+        for k in range(self.n_in):
+            self.lib.mmo_encrypt_symmetric(self.o.p, 0, A(sk), A(a[k]), A(e[k]), A(pts[k]), self.o.N, A(cts[k]))
+        return cts
+
+    def server(self, in_cts, share_pts, wpts, pk1, u, e1, mask):
+        o, lib, N, L = self.o, self.lib, self.o.N, self.o.L
+        inp = in_cts.copy()
+        if self.shared:
+            for k in range(self.n_in):
+                lib.mmo_add_plain(o.p, 0, A(inp[k]), A(share_pts[k]), N)
+        out = np.zeros((self.n_out, 2, L, N), np.uint64)
+        tmp = np.zeros((2, L, N), np.uint64)
+        for j in range(self.n_out):                                      # :443-457
+            lib.mmo_multiply_plain(o.p, 0, A(inp[0]), A(wpts[j, 0]), N, A(out[j]))
+            for i in range(1, self.n_in):
+                lib.mmo_multiply_plain(o.p, 0, A(inp[i]), A(wpts[j, i]), N, A(tmp))
+                lib.mmo_ct_add(o.p, 0, A(out[j]), A(tmp), 2)
+        low = np.zeros((self.n_out, 2, 1, N), np.uint64)
+        share = np.zeros(self.rows, np.uint64)
+        zero = np.zeros((2, 1, N), np.uint64)
+        targets = np.arange(self.d0, dtype=np.int64) * self.d1           # :482-485
+        q0 = np.uint64(o.q[0])
+        for j in range(self.n_out):                                      # :494-511
+            lib.mmo_mod_switch_to_last(o.p, A(out[j]), A(low[j]), 2)
+            lib.mmo_encrypt_zero_asymmetric(o.p, 1, A(pk1), A(u[j]), None, A(e1[j]), A(zero))
+            lib.mmo_ct_add(o.p, 1, A(low[j]), A(zero), 2)
+            r = mask[j]
+            gathered = np.ascontiguousarray(r[targets])
+            coeffs = np.zeros(len(targets), np.uint64)
+            lib.mmo_decrypt_scale_and_round(o.p, 1, A(gathered), len(targets), A(coeffs))
+            low[j, 0, 0] = np.where(low[j, 0, 0] >= r, low[j, 0, 0] - r, low[j, 0, 0] + q0 - r)
+            r0, r1 = j * self.d0, min((j + 1) * self.d0, self.rows)
+            share[r0:r1] = coeffs[:r1 - r0]
+        m0, m1 = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        lib.mmo_truncate_masks(o.p, A(m0), A(m1))
+        low[:, 0] &= m0[0]
+        low[:, 1] &= m1[0]
+        for j in range(self.n_out):                                      # :538-556
+            r0, r1 = j * self.d0, min((j + 1) * self.d0, self.rows)
+            upper = (r1 - r0) * self.d1
+            idx = np.arange(N)
+            keep = (idx < upper) & (idx % self.d1 == 0)
+            low[j, 0, 0, ~keep] = 0
+        return low, share
+
+    def decrypt(self, sk1, cts):
+        out = np.zeros(self.rows, np.uint64)
+        pt = np.zeros(self.o.N, np.uint64)
+        for j in range(self.n_out):                                      # :589-599
+            self.lib.mmo_decrypt(self.o.p, 1, A(sk1), A(cts[j]), A(pt))
+            r0, r1 = j * self.d0, min((j + 1) * self.d0, self.rows)
+            out[r0:r1] = pt[(np.arange(r1 - r0)) * self.d1]
+        return out
+
+
+class BnOracle:
+    """HomBNSS SIMD path (hom_bn_ss.cc:151-406) on an oracle context with t = p."""
+
+    def __init__(self, o, n):
+        self.o, self.lib, self.n = o, load(), n
+        self.sub = min(n, o.N)
+        self.n_ct = -(-n // self.sub)
+
+    def encode(self, vec):
+        N = self.o.N
+        out = np.zeros((self.n_ct, N), np.uint64)
+        for k in range(self.n_ct):
+            chunk = np.zeros(N, np.uint64)
+            part = vec[k * self.sub:min((k + 1) * self.sub, self.n)]
+            chunk[:len(part)] = part
+            self.lib.mmo_batch_encode(self.o.p, A(chunk), N, A(out[k]))
+        return out
+
+    def encrypt(self, sk, vec, a, e):
+        pts = self.encode(vec)
+        cts = np.zeros((self.n_ct, 2, self.o.L, self.o.N), np.uint64)
+        for k in range(self.n_ct):
+            self.lib.mmo_encrypt_symmetric(self.o.p, 0, A(sk), A(a[k]), A(e[k]), A(pts[k]), self.o.N, A(cts[k]))
+        return cts
+
+    def _tail(self, acc, random):
+        o, lib, N, p = self.o, self.lib, self.o.N, np.uint64(self.o.t)
+        low = np.zeros((self.n_ct, 2, 1, N), np.uint64)
+        for k in range(self.n_ct):
+            lib.mmo_mod_switch_to_last(o.p, A(acc[k]), A(low[k]), 2)    # :269 / :307
+        r = random % p                                                  # :333-334
+        share = np.where(r != 0, p - r, np.uint64(0))                   # :338-340
+        rpts = self.encode(r)
+        m0, m1 = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        lib.mmo_truncate_masks(o.p, A(m0), A(m1))
+        for k in range(self.n_ct):                                      # :346-357
+            lib.mmo_add_plain(o.p, 1, A(low[k]), A(rpts[k]), N)
+        low[:, 0] &= m0[0]
+        low[:, 1] &= m1[0]
+        return low, share
+
+    def bn(self, cts, share_pts, scale_pts, random):
+        o, lib, N = self.o, self.lib, self.o.N
+        acc = cts.copy()
+        for k in range(self.n_ct):                                      # :262-268
+            if share_pts is not None:
+                lib.mmo_add_plain(o.p, 0, A(acc[k]), A(share_pts[k]), N)
+            lib.mmo_multiply_plain(o.p, 0, A(acc[k]), A(scale_pts[k]), N, A(acc[k]))
+        return self._tail(acc, random)
+
+    def bole(self, ex, ey, px, py, random):
+        o, lib, N = self.o, self.lib, self.o.N
+        acc = np.zeros_like(ex)
+        tmp = np.zeros_like(ex[0])
+        for k in range(self.n_ct):                                      # :303-307
+            lib.mmo_multiply_plain(o.p, 0, A(ex[k]), A(py[k]), N, A(acc[k]))
+            lib.mmo_multiply_plain(o.p, 0, A(ey[k]), A(px[k]), N, A(tmp))
+            lib.mmo_ct_add(o.p, 0, A(acc[k]), A(tmp), 2)
+        return self._tail(acc, random)
+
+    def decrypt(self, sk1, cts):
+        N = self.o.N
+        out = np.zeros(self.n, np.uint64)
+        pt, slots = np.zeros(N, np.uint64), np.zeros(N, np.uint64)
+        for k in range(self.n_ct):                                      # :385-392
+            self.lib.mmo_decrypt(self.o.p, 1, A(sk1), A(cts[k]), A(pt))
+            self.lib.mmo_batch_decode(self.o.p, A(pt), A(slots))
+            lo, hi = k * self.sub, min((k + 1) * self.sub, self.n)
+            out[lo:hi] = slots[:hi - lo]
+        return out

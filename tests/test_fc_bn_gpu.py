@@ -1,0 +1,166 @@
+"""GPU parity of the HomFCSS and HomBNSS (BOLE) layer calls vs the oracle flows, bit for bit."""
+import numpy as np
+import pytest
+
+from tests.layer_fixtures import SEED, keypair, noise, rns_uniform, signed_weights, ternary
+from tests.oracle_binding import OracleCtx, splitmix64, uniform_mod
+from tests.oracle_layers import BnOracle, FcOracle
+
+pytestmark = pytest.mark.gpu
+T = 1 << 37
+P32 = 4293918721
+N = 4096
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import torch
+    assert torch.cuda.is_available()
+    import openmm_amd
+    return openmm_amd
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("rows,cols,shared", [(10, 37, True), (70, 300, True), (5, 5000, False), (200, 64, True),
+                                              (1001, 2048, True), (1, 1, True), (4096, 1, True)])
+def test_fc_layer_bit_exact(mm, rows, cols, shared):
+    from openmm_amd.hom_fc_ss import HomFCSS, Meta
+    o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
+    fc = FcOracle(o, rows, cols, shared)
+    meta = Meta((rows, cols), (cols,), shared)
+    sk, pk = keypair(o)
+    client, server = HomFCSS(), HomFCSS()
+    client.setUp(g, sk_ntt=dev(sk))
+    server.setUp(g, pk_ntt=dev(pk))
+    plan = server.plan(meta)
+    assert plan.split == (fc.d0, fc.d1) and (plan.n_in, plan.n_out) == (fc.n_in, fc.n_out)
+    vec = uniform_mod(SEED + 1, cols, T)
+    vec[:min(3, cols)] = [0, 1, T - 1][:min(3, cols)]
+    s0 = uniform_mod(SEED + 2, cols, T)
+    s1 = (vec - s0) & np.uint64(T - 1)
+    W = signed_weights(SEED + 3, (rows, cols), 1 << 12, T)
+    W[W == 0] = 1  # a block that encodes to zero is rejected (hom_fc_ss.cc:414-422)
+    a, e = rns_uniform(o, SEED + 4, fc.n_in, 2), noise(SEED + 5, (fc.n_in, N))
+    cin = s0 if shared else vec
+    ref_cts = fc.encrypt_input(sk, cin, a, e)
+    got_cts = client.encryptInputVector(dev(cin), meta, (dev(a), dev(e)))
+    assert np.array_equal(host(got_cts), ref_cts)
+    ref_w, got_w = fc.encode_weights(W), server.encodeWeightMatrix(dev(W), meta)
+    assert np.array_equal(host(got_w), ref_w)
+    ref_s = got_s = None
+    if shared:
+        ref_s, got_s = fc.encode_input(s1), server.encodeInputVector(dev(s1), meta)
+        assert np.array_equal(host(got_s), ref_s)
+    u, e1 = ternary(SEED + 6, (fc.n_out, N)), noise(SEED + 7, (fc.n_out, N))
+    mask = rns_uniform(o, SEED + 8, fc.n_out, 1)[:, 0]
+    ref_out, ref_share = fc.server(ref_cts, ref_s, ref_w, np.ascontiguousarray(pk[:, :1]), u, e1, mask)
+    got_out, got_share = server.matVecMul(got_w, got_cts, got_s, meta, (dev(u), dev(e1), dev(mask)))
+    assert np.array_equal(host(got_out), ref_out)
+    assert np.array_equal(host(got_share), ref_share)
+    got_dec = host(client.decryptToVector(got_out, meta))
+    assert np.array_equal(got_dec, fc.decrypt(np.ascontiguousarray(sk[:1]), ref_out))
+    ideal = (W.astype(object) @ vec.astype(object)) % T
+    diff = (got_dec.astype(object) + host(got_share).astype(object) - ideal) % T
+    assert all(d in (0, 1, T - 1) for d in diff)
+
+
+def test_fc_rejects_zero_block(mm):
+    import torch
+    from openmm_amd.hom_fc_ss import HomFCSS, Meta
+    g = mm.Context(N, (60, 49), T)
+    h = HomFCSS()
+    h.setUp(g, pk_ntt=torch.zeros((2, 2, N), dtype=torch.int64, device="cuda"))
+    meta = Meta((4, 8), (8,), False)
+    p = h.plan(meta)
+    w = torch.zeros((p.n_out, p.n_in, N), dtype=torch.int64, device="cuda")
+    cts = torch.zeros((p.n_in, 2, 2, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(mm.MMHError) as ei:
+        h.matVecMul(w, cts, None, meta, (None, None, None))
+    assert ei.value.code == 7  # ERR_INVALID_ARG, hom_fc_ss.cc:419
+
+
+@pytest.mark.parametrize("n", [1, 100, 4096, 10000])
+def test_bole_bn_bit_exact(mm, n):
+    from openmm_amd.hom_bn_ss import HomBNSS, Meta
+    from openmm_amd.truncation import bole_cross_term
+    o, g = OracleCtx(N, (60, 49), P32), mm.Context(N, (60, 49), P32)
+    bn = BnOracle(o, n)
+    meta = Meta((n,), P32, True)
+    sk, _ = keypair(o)
+    sk1 = np.ascontiguousarray(sk[:1])
+    client, server = HomBNSS(), HomBNSS()
+    client.setUp_Field(P32, g, sk_ntt=dev(sk))
+    server.setUp_Field(P32, g)
+    # ring_to_field outputs are only congruent mod p: feed values in [0, 2^32)
+    x0, y0, x1, y1 = (splitmix64(SEED + i, n) & np.uint64((1 << 32) - 1) for i in range(4))
+    ax, ex_ = rns_uniform(o, SEED + 10, bn.n_ct, 2), noise(SEED + 11, (bn.n_ct, N))
+    ay, ey_ = rns_uniform(o, SEED + 12, bn.n_ct, 2), noise(SEED + 13, (bn.n_ct, N))
+    ref_ex, ref_ey = bn.encrypt(sk, x0, ax, ex_), bn.encrypt(sk, y0, ay, ey_)
+    got_ex = client.encryptVector(dev(x0), meta, (dev(ax), dev(ex_)))
+    got_ey = client.encryptVector(dev(y0), meta, (dev(ay), dev(ey_)))
+    assert np.array_equal(host(got_ex), ref_ex) and np.array_equal(host(got_ey), ref_ey)
+    ref_px, ref_py = bn.encode(x1), bn.encode(y1)
+    got_px, got_py = server.encodeVector(dev(x1), meta), server.encodeVector(dev(y1), meta)
+    assert np.array_equal(host(got_px), ref_px) and np.array_equal(host(got_py), ref_py)
+    random = splitmix64(SEED + 14, n)
+    ref_out, ref_share = bn.bole(ref_ex, ref_ey, ref_px, ref_py, random)
+    got_out, got_share = server.bole(got_ex, got_ey, got_px, got_py, meta, dev(random))
+    assert np.array_equal(host(got_out), ref_out) and np.array_equal(host(got_share), ref_share)
+    assert np.array_equal(host(got_ex), ref_ex)  # inputs are not destroyed
+    got_dec = client.decryptToVector(got_out, meta)
+    assert np.array_equal(host(got_dec), bn.decrypt(sk1, ref_out))
+    # CheetahLinear::BOLE tail on both sides (cheetah-api.cpp:648-649) and the protocol identity
+    # tests/bole_test.cpp:164-167: out0 + out1 = (x0 + x1) * (y0 + y1) mod p
+    out_b = bole_cross_term(got_dec.clone(), dev(x0), dev(y0), P32)
+    out_a = bole_cross_term(got_share.clone(), dev(x1), dev(y1), P32)
+    want = ((x0.astype(object) + x1.astype(object)) * (y0.astype(object) + y1.astype(object))) % P32
+    assert np.array_equal((host(out_a).astype(object) + host(out_b).astype(object)) % P32, want)
+    # bn with the scale vector in clear on the server (cheetah-api.cpp:527)
+    scale = uniform_mod(SEED + 20, n, P32)
+    ref_sc, got_sc = bn.encode(scale), server.encodeScales(dev(scale), meta)
+    ref_out, ref_share = bn.bn(ref_ex, ref_px, ref_sc, random)
+    got_out, got_share = server.bn(got_ex, got_px, got_sc, meta, dev(random))
+    assert np.array_equal(host(got_out), ref_out) and np.array_equal(host(got_share), ref_share)
+    meta_ns = Meta((n,), P32, False)
+    ref_out, ref_share = bn.bn(ref_ex, None, ref_sc, random)
+    got_out, got_share = server.bn(got_ex, None, got_sc, meta_ns, dev(random))
+    assert np.array_equal(host(got_out), ref_out) and np.array_equal(host(got_share), ref_share)
+
+
+def test_bole_full_size_identity(mm):
+    """bole_test flags 1 1 size: 2^20 elements, l=32, |x|,|y| < 2^12 (tests/bole_test.cpp:78,98,568)"""
+    import torch
+    from openmm_amd.hom_bn_ss import HomBNSS, Meta
+    from openmm_amd.truncation import bole_cross_term
+    g = mm.Context(N, (60, 49), P32)
+    o = OracleCtx(N, (60, 49), P32)
+    sk, _ = keypair(o)
+    n = 1 << 20
+    n_ct = n // N
+    meta = Meta((n,), P32, True)
+    client, server = HomBNSS(), HomBNSS()
+    client.setUp_Field(P32, g, sk_ntt=dev(sk))
+    server.setUp_Field(P32, g)
+    gen = torch.Generator(device="cuda").manual_seed(SEED)
+    rnd = lambda lo, hi, *shape: torch.randint(lo, hi, shape, dtype=torch.int64, device="cuda", generator=gen)
+    x, y = rnd(-(1 << 12), 1 << 12, n), rnd(-(1 << 12), 1 << 12, n)
+    x0, y0 = rnd(0, P32, n), rnd(0, P32, n)
+    x1, y1 = (x - x0) % P32, (y - y0) % P32
+    qs = torch.tensor(g.q, dtype=torch.int64, device="cuda").view(1, 2, 1)
+    ex = client.encryptVector(x0, meta, (rnd(0, 1 << 62, n_ct, 2, N) % qs, rnd(-8, 9, n_ct, N)))
+    ey = client.encryptVector(y0, meta, (rnd(0, 1 << 62, n_ct, 2, N) % qs, rnd(-8, 9, n_ct, N)))
+    out_cts, share = server.bole(ex, ey, server.encodeVector(x1, meta), server.encodeVector(y1, meta), meta,
+                                 rnd(0, 1 << 62, n))
+    dec = client.decryptToVector(out_cts, meta)
+    out_b = bole_cross_term(dec, x0, y0, P32)
+    out_a = bole_cross_term(share, x1, y1, P32)
+    assert torch.equal((out_a + out_b) % P32, (x * y) % P32)

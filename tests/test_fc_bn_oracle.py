@@ -1,0 +1,59 @@
+"""CPU: oracle FC and BN/BOLE flows meet the reference's acceptance identities."""
+import numpy as np
+import pytest
+
+from tests.layer_fixtures import SEED, keypair, noise, rns_uniform, signed_weights, ternary
+from tests.oracle_binding import OracleCtx, splitmix64, uniform_mod
+from tests.oracle_layers import BnOracle, FcOracle
+
+T = 1 << 37
+P32 = 4293918721
+N = 4096
+
+
+def test_fc_split_matches_survey():
+    o = OracleCtx(N, (60, 49), T)
+    fc = FcOracle(o, 1001, 2048, True)
+    assert (fc.d0, fc.d1, fc.n_in, fc.n_out) == (39, 103, 20, 26)
+
+
+@pytest.mark.parametrize("rows,cols,shared", [(10, 37, True), (70, 300, True), (5, 5000, False), (200, 64, True)])
+def test_fc_flow_reconstructs(rows, cols, shared):
+    o = OracleCtx(N, (60, 49), T)
+    fc = FcOracle(o, rows, cols, shared)
+    sk, pk = keypair(o)
+    vec = uniform_mod(SEED + 1, cols, T)
+    s0 = uniform_mod(SEED + 2, cols, T)
+    s1 = (vec - s0) & np.uint64(T - 1)
+    W = signed_weights(SEED + 3, (rows, cols), 1 << 12, T)
+    cts = fc.encrypt_input(sk, s0 if shared else vec, rns_uniform(o, SEED + 4, fc.n_in, 2), noise(SEED + 5, (fc.n_in, N)))
+    out_cts, share = fc.server(cts, fc.encode_input(s1) if shared else None, fc.encode_weights(W),
+                               np.ascontiguousarray(pk[:, :1]), ternary(SEED + 6, (fc.n_out, N)),
+                               noise(SEED + 7, (fc.n_out, N)), rns_uniform(o, SEED + 8, fc.n_out, 1)[:, 0])
+    dec = fc.decrypt(np.ascontiguousarray(sk[:1]), out_cts)
+    ideal = (W.astype(object) @ vec.astype(object)) % T
+    diff = (dec.astype(object) + share.astype(object) - ideal) % T
+    assert all(d in (0, 1, T - 1) for d in diff)                       # library_fixed_uniform_cheetah.cpp:404
+
+
+@pytest.mark.parametrize("n", [100, 4096, 10000])
+def test_bole_and_bn_flow_reconstruct(n):
+    """tests/bole_test.cpp:164-167: exact reconstruction of the cross terms x0*y1 + x1*y0"""
+    o = OracleCtx(N, (60, 49), P32)
+    bn = BnOracle(o, n)
+    sk, _ = keypair(o)
+    sk1 = np.ascontiguousarray(sk[:1])
+    x0, y0, x1, y1 = (uniform_mod(SEED + i, n, P32) for i in range(4))
+    ex = bn.encrypt(sk, x0, rns_uniform(o, SEED + 10, bn.n_ct, 2), noise(SEED + 11, (bn.n_ct, N)))
+    ey = bn.encrypt(sk, y0, rns_uniform(o, SEED + 12, bn.n_ct, 2), noise(SEED + 13, (bn.n_ct, N)))
+    random = splitmix64(SEED + 14, n)
+    out_cts, share = bn.bole(ex, ey, bn.encode(x1), bn.encode(y1), random)
+    dec = bn.decrypt(sk1, out_cts)
+    want = (x0.astype(object) * y1.astype(object) + y0.astype(object) * x1.astype(object)) % P32
+    assert np.array_equal((dec.astype(object) + share.astype(object)) % P32, want)
+    # bn: (x0 + x1) * scale
+    scale = uniform_mod(SEED + 20, n, P32)
+    out_cts, share = bn.bn(ex, bn.encode(x1), bn.encode(scale), random)
+    dec = bn.decrypt(sk1, out_cts)
+    want = ((x0.astype(object) + x1.astype(object)) * scale.astype(object)) % P32
+    assert np.array_equal((dec.astype(object) + share.astype(object)) % P32, want)
