@@ -37,6 +37,61 @@ def cpu_baseline(seconds=12.0):
             "sample": f"{done} forward limb-NTTs N=4096 (oracle Harvey/Shoup C, OpenMP) in {dt:.1f}s"}
 
 
+def layer_legs(torch, openmm_amd, local):
+    """Secondary legs of BASELINE.json's metric (configs[2]): server-side HomConv of the ResNet50
+    3x3 56x56x64->64 layer and BOLE on 2^20 elements, ms per layer, inputs resident in HBM."""
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta, SAME
+    from openmm_amd.hom_bn_ss import HomBNSS, Meta as BnMeta
+    out = {}
+    gen = torch.Generator(device="cuda").manual_seed(0x4D264D)
+    rnd = lambda lo, hi, *shape: torch.randint(lo, hi, shape, dtype=torch.int64, device="cuda", generator=gen)
+
+    def ms(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t, N = 1 << 37, 4096
+    ctx = openmm_amd.Context(N, (60, 49), t, device=local)
+    qs = torch.tensor(ctx.q, dtype=torch.int64, device="cuda").view(1, 2, 1)
+    meta = Meta((64, 56, 56), (64, 3, 3), 64, SAME, 1, True)
+    srv = HomConv2DSS()
+    srv.setUp(ctx, pk_ntt=rnd(0, 1 << 62, 2, 2, N) % qs)
+    plan = srv.plan(meta)
+    cts = rnd(0, 1 << 62, plan.n_in, 2, 2, N) % qs.view(1, 1, 2, 1)
+    share = rnd(0, t, 64, 56, 56)
+    filters = (rnd(-(1 << 12) + 1, 1 << 12, 64, 64, 3, 3) | 1) & (t - 1)
+    rand = (rnd(-1, 2, plan.n_out, N), rnd(-8, 9, plan.n_out, N), rnd(0, 1 << 62, plan.n_out, N) % ctx.q[0])
+
+    def conv_layer():  # what CheetahLinear::conv2d runs on the server per layer (cheetah-api.cpp:417-445)
+        f = srv.encodeFilters(filters, meta)
+        s = srv.encodeImage(share, meta)
+        return srv.conv2DSS(cts, s, f, meta, rand)
+
+    out["homconv_resnet50_3x3_56x56x64_ms"] = ms(conv_layer)
+    out["homconv_reference_schedule_ntts"] = 40960
+    p = 4293918721
+    bctx = openmm_amd.Context(N, (60, 49), p, device=local)
+    bn = HomBNSS()
+    bn.setUp_Field(p, bctx)
+    n = 1 << 20
+    bmeta = BnMeta((n,), p, True)
+    ex, ey = (rnd(0, 1 << 62, n // N, 2, 2, N) % qs.view(1, 1, 2, 1) for _ in range(2))
+    x1, y1, rr = rnd(0, 1 << 32, n), rnd(0, 1 << 32, n), rnd(0, 1 << 62, n)
+
+    def bole_layer():  # ALICE branch of CheetahLinear::BOLE (cheetah-api.cpp:627-645)
+        return bn.bole(ex, ey, bn.encodeVector(x1, bmeta), bn.encodeVector(y1, bmeta), bmeta, rr)
+
+    out["bole_2p20_server_ms"] = ms(bole_layer)
+    return out
+
+
 def timed(fn, steps, warmup, torch, dist, world):
     for _ in range(warmup):
         fn()
@@ -106,6 +161,9 @@ def main():
         extra["ntt8192_per_s"] = d8.shape[0] * 4 / f8
         extra["intt8192_per_s"] = d8.shape[0] * 4 / i8
         extra["ntt8192_hbm_frac"] = d8.shape[0] * 4 * BYTES_PER_NTT[8192] / f8 / HBM_PEAK
+        del d8, c8
+        if world == 1:
+            extra.update(layer_legs(torch, openmm_amd, local))
 
     if rank == 0:
         line = {

@@ -705,3 +705,35 @@ void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, si
 #pragma omp parallel for num_threads(threads) schedule(static)
   for (long b = 0; b < total; b++) inv(c, (size_t)b % limbs, polys + (size_t)b * c->N);
 }
+
+/* conv2DOneFilter for every filter (hom_conv2d_ss.cc:563-619, :679-690) in the reference's own
+ * schedule -- one multiply_plain (+ add_inplace) per (filter, channel slice, spatial slice), workers
+ * over filters like its ThreadPool.  image [Cs*S] cts at level 0, filters [M][Cs] plaintexts,
+ * out [M*S] cts.  Used for parity of large layers and as the timed CPU baseline. */
+void mmo_conv_mac_reference(const mmo_ctx *c, const uint64_t *image, const uint64_t *filters, size_t M,
+                            size_t Cs, size_t S, uint64_t *out, int threads) {
+  const size_t N = c->N, ct = 2 * c->L * N;
+#pragma omp parallel for num_threads(threads) schedule(dynamic)
+  for (long m = 0; m < (long)M; m++) {
+    uint64_t *tmp = (uint64_t *)malloc(ct * 8);
+    for (size_t i = 0; i < S; i++) {
+      int started = 0;
+      uint64_t *dst = out + ((size_t)m * S + i) * ct;
+      for (size_t cc = 0; cc < Cs; cc++) {
+        const uint64_t *pt = filters + ((size_t)m * Cs + cc) * N;
+        int nz = 0;
+        for (size_t k = 0; k < N && !nz; k++) nz = pt[k] != 0;
+        if (!nz) continue;
+        const uint64_t *src = image + (cc * S + i) * ct;
+        if (started) {
+          mmo_multiply_plain(c, 0, src, pt, N, tmp);
+          mmo_ct_add(c, 0, dst, tmp, 2);
+        } else {
+          mmo_multiply_plain(c, 0, src, pt, N, dst);
+          started = 1;
+        }
+      }
+    }
+    free(tmp);
+  }
+}

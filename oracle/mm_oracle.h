@@ -192,6 +192,8 @@ long mmo_fc_encode_weights(long N, uint64_t t, const uint64_t *W, long nrows, lo
 /* ---- timed CPU baseline helpers (bench.py cpu_baseline leg): OpenMP over independent polys */
 void mmo_ntt_forward_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
 void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
+void mmo_conv_mac_reference(const mmo_ctx *c, const uint64_t *image, const uint64_t *filters, size_t M,
+                            size_t Cs, size_t S, uint64_t *out, int threads);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,7 @@ def load():
         lib.mmo_bole_cross_term.argtypes = [vp, vp, vp, sz, u64]
         lib.mmo_ntt_forward_batch.argtypes = [P, vp, sz, sz, ci]
         lib.mmo_ntt_inverse_batch.argtypes = [P, vp, sz, sz, ci]
+        lib.mmo_conv_mac_reference.argtypes = [P, vp, vp, sz, sz, sz, vp, ci]
         _lib = lib
     return _lib
 

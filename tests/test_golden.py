@@ -1,0 +1,75 @@
+"""The committed golden vectors (tests/golden/vectors.json, made by make_golden.py from the
+oracle) still match what the oracle computes today."""
+import json
+import os
+
+from tests.golden.make_golden import build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_oracle_reproduces_golden_vectors():
+    want = json.load(open(os.path.join(HERE, "golden", "vectors.json")))
+    got = json.loads(json.dumps(build()))
+    assert got == want
+
+
+import hashlib
+
+import numpy as np
+import pytest
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_vectors():
+    """HIP path vs the committed fixtures directly (no oracle in the loop)."""
+    import torch
+    import openmm_amd
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    from openmm_amd.lib import to_device, to_host
+    from tests.layer_fixtures import SEED, noise, rns_uniform, signed_weights, ternary
+    from tests.oracle_binding import OracleCtx, uniform_mod
+    want = json.load(open(os.path.join(HERE, "golden", "vectors.json")))
+    g = openmm_amd.Context(4096, (60, 49), 1 << 37)
+    assert g.q == want["params"]["q4096"] and g.psi == want["params"]["psi4096"]
+    assert g.gamma == want["params"]["gamma4096"]
+    g8 = openmm_amd.Context(8192, (60, 60, 60, 49), 0)
+    assert g8.q == want["params"]["q8192"] and g8.psi == want["params"]["psi8192"]
+
+    class Q:  # only the moduli are needed to regenerate the seeded inputs
+        N, q = 4096, g.q
+    d = to_device(rns_uniform(Q, SEED, 2, 2))
+    assert _sha(to_host(g.ntt_forward(d))) == want["ntt4096_forward"]["sha256"]
+    a8 = np.stack([np.stack([uniform_mod(SEED + l, 8192, q) for l, q in enumerate(g8.q)])])
+    assert _sha(to_host(g8.ntt_forward(to_device(a8)))) == want["ntt8192_forward"]["sha256"]
+    # the small conv layer end to end, keys regenerated through the C ABI
+    t, N = 1 << 37, 4096
+    s = (np.array([int(x) for x in __import__("tests.oracle_binding", fromlist=["splitmix64"]).splitmix64(SEED, N)
+                   % np.uint64(3)], dtype=np.int64) - 1)
+    sk = np.stack([np.where(s < 0, np.uint64(q - 1), s.astype(np.uint64)) for q in g.q]).astype(np.uint64)
+    d_sk = g.ntt_forward(to_device(sk))
+    a_ntt = np.stack([uniform_mod(SEED + 1 + l, N, q) for l, q in enumerate(g.q)])
+    d_pk = g.make_public_key(d_sk, to_device(a_ntt), torch.from_numpy(noise(SEED + 9, N)).cuda())
+    meta = Meta((5, 12, 12), (5, 3, 3), 2, 1, 1, True)
+    client, server = HomConv2DSS(), HomConv2DSS()
+    client.setUp(g, sk_ntt=d_sk)
+    server.setUp(g, pk_ntt=d_pk)
+    plan = server.plan(meta)
+    img, s0 = uniform_mod(SEED + 20, (5, 12, 12), t), uniform_mod(SEED + 21, (5, 12, 12), t)
+    s1 = (img - s0) & np.uint64(t - 1)
+    f = signed_weights(SEED + 22, (2, 5, 3, 3), 1 << 12, t)
+    dev_i = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    cts = client.encryptImage(to_device(s0), meta, (to_device(rns_uniform(Q, SEED + 30, plan.n_in, 2)),
+                                                    dev_i(noise(SEED + 31, (plan.n_in, N)))))
+    fp = server.encodeFilters(to_device(f), meta)
+    assert _sha(to_host(fp)) == want["conv_5x12x12_3x3_same"]["filters"]["sha256"]
+    oc, sh = server.conv2DSS(cts, server.encodeImage(to_device(s1), meta), fp, meta,
+                             (dev_i(ternary(SEED + 40, (plan.n_out, N))), dev_i(noise(SEED + 41, (plan.n_out, N))),
+                              to_device(rns_uniform(Q, SEED + 50, plan.n_out, 1)[:, 0])))
+    assert _sha(to_host(oc)) == want["conv_5x12x12_3x3_same"]["out_cts"]["sha256"]
+    assert _sha(to_host(sh)) == want["conv_5x12x12_3x3_same"]["share"]["sha256"]
+    assert _sha(to_host(client.decryptToTensor(oc, meta))) == want["conv_5x12x12_3x3_same"]["decrypted"]["sha256"]
