@@ -1,0 +1,76 @@
+// gemini::CheetahLinear over libmm_hip: same public surface as the reference class
+// (SCI/src/cheetah/cheetah-api.h:16-98) with mm::IOChannel in place of sci::NetIO.
+// Callers written against the reference (Conv2DWrapper, MatMul2D, ElemWiseActModelVectorMult in
+// SCI/src/library_fixed_uniform_cheetah.cpp; tests/bole_test.cpp) use it the same way.
+// Both parties must run this implementation: ciphertexts travel as raw coefficient arrays, not
+// in SEAL's serialisation.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "mm_gemini/core.h"
+#include "mm_gemini/io.h"
+
+struct mmh_ctx;
+
+namespace gemini {
+
+struct HomConv2DSS {
+  struct Meta {  // include/gemini/cheetah/hom_conv2d_ss.h:35-42
+    TensorShape ishape;
+    TensorShape fshape;
+    size_t n_filters;
+    Padding padding;
+    size_t stride;
+    bool is_shared_input;
+  };
+};
+struct HomFCSS {
+  struct Meta {  // hom_fc_ss.h:34-38
+    TensorShape input_shape;
+    TensorShape weight_shape;
+    bool is_shared_input;
+  };
+};
+struct HomBNSS {
+  struct Meta {  // hom_bn_ss.h:33-38
+    TensorShape ishape;
+    TensorShape vec_shape;
+    uint64_t target_base_mod;
+    bool is_shared_input;
+  };
+};
+
+class CheetahLinear {
+ public:
+  using ConvMeta = HomConv2DSS::Meta;
+  using FCMeta = HomFCSS::Meta;
+  using BNMeta = HomBNSS::Meta;
+
+  // party: 1 = ALICE (server, model owner), 2 = BOB (client, key owner)  -- sci::ALICE / sci::BOB
+  CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, size_t nthreads = 1, int device = 0);
+  ~CheetahLinear();
+  CheetahLinear(const CheetahLinear &) = delete;
+
+  void conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<Tensor<uint64_t>> &filters,
+              const ConvMeta &meta, Tensor<uint64_t> &out_tensor) const;
+  void fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
+          Tensor<uint64_t> &out_vec_share) const;
+  void bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &scale_vector, const BNMeta &meta,
+          Tensor<uint64_t> &out_vector) const;
+  void BOLE(const Tensor<uint64_t> &input_x_vector, const Tensor<uint64_t> &input_y_vector, const BNMeta &meta,
+            Tensor<uint64_t> &out_vector) const;
+
+  uint64_t io_counter() const { return io_ ? io_->counter : 0; }
+  int party() const { return party_; }
+  uint64_t field_mod() const { return field_mod_; }
+
+ private:
+  struct Impl;
+  int party_;
+  mm::IOChannel *io_;
+  uint64_t base_mod_, field_mod_ = 0;
+  std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace gemini

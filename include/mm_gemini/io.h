@@ -1,0 +1,119 @@
+// The two host-side services the path needs from its caller, as abstract interfaces:
+//  * a byte channel with the surface CheetahLinear uses on sci::NetIO
+//    (SCI/src/utils/net_io_channel.h:63-163: send_data / recv_data / flush / counter), and
+//  * the correlated-OT calls Truncation makes on otpack->iknp_straight
+//    (SCI/src/OT/ferret/silent_ot.h:85-242).
+// Production code adapts sci::NetIO and SilentOT to these in a dozen lines; the in-process
+// implementations below are test doubles (LoopbackIO; IdealCOT in the style of
+// SCI/src/OT/ideal.h:106-156).
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <vector>
+
+namespace mm {
+
+class IOChannel {
+ public:
+  virtual ~IOChannel() = default;
+  virtual void send_data(const void *data, size_t nbytes) = 0;
+  virtual void recv_data(void *data, size_t nbytes) = 0;
+  virtual void flush() {}
+  uint64_t counter = 0;  // bytes sent, as sci::IOChannel::counter (io_channel.h:41-45)
+};
+
+// One direction of an in-process byte pipe.
+class BytePipe {
+ public:
+  void push(const void *p, size_t n) {
+    std::lock_guard<std::mutex> g(m_);
+    const uint8_t *b = static_cast<const uint8_t *>(p);
+    q_.insert(q_.end(), b, b + n);
+    cv_.notify_all();
+  }
+  void pop(void *p, size_t n) {
+    std::unique_lock<std::mutex> g(m_);
+    cv_.wait(g, [&] { return q_.size() >= n; });
+    std::copy(q_.begin(), q_.begin() + n, static_cast<uint8_t *>(p));
+    q_.erase(q_.begin(), q_.begin() + n);
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<uint8_t> q_;
+};
+
+class LoopbackIO : public IOChannel {
+ public:
+  LoopbackIO(std::shared_ptr<BytePipe> tx, std::shared_ptr<BytePipe> rx) : tx_(tx), rx_(rx) {}
+  static std::pair<std::unique_ptr<LoopbackIO>, std::unique_ptr<LoopbackIO>> MakePair() {
+    auto a = std::make_shared<BytePipe>(), b = std::make_shared<BytePipe>();
+    return {std::make_unique<LoopbackIO>(a, b), std::make_unique<LoopbackIO>(b, a)};
+  }
+  void send_data(const void *d, size_t n) override {
+    tx_->push(d, n);
+    counter += n;
+  }
+  void recv_data(void *d, size_t n) override { rx_->pop(d, n); }
+
+ private:
+  std::shared_ptr<BytePipe> tx_, rx_;
+};
+
+// Correlated OT as Truncation uses it: sender gets random x, receiver gets x + b*corr.
+class COT {
+ public:
+  virtual ~COT() = default;
+  virtual void send_cot(uint64_t *data0, const uint64_t *corr, int n, int l) = 0;
+  virtual void recv_cot(uint64_t *data, const bool *b, int n, int l) = 0;
+  virtual void send_cot_prime(uint64_t *data0, const uint64_t *corr, int n, uint64_t p) = 0;
+  virtual void recv_cot_prime(uint64_t *data, const bool *b, int n, uint64_t p) = 0;
+  virtual void flush() {}
+};
+
+// Ideal functionality over a shared in-process mailbox (sender posts (x, corr), receiver combines).
+class IdealCOT : public COT {
+ public:
+  struct Mailbox {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::pair<std::vector<uint64_t>, std::vector<uint64_t>>> q;
+  };
+  IdealCOT(std::shared_ptr<Mailbox> box, uint64_t seed) : box_(box), rng_(seed) {}
+  void send_cot(uint64_t *d, const uint64_t *corr, int n, int l) override { send(d, corr, n, l, 0); }
+  void recv_cot(uint64_t *d, const bool *b, int n, int l) override { recv(d, b, n, l, 0); }
+  void send_cot_prime(uint64_t *d, const uint64_t *corr, int n, uint64_t p) override { send(d, corr, n, 0, p); }
+  void recv_cot_prime(uint64_t *d, const bool *b, int n, uint64_t p) override { recv(d, b, n, 0, p); }
+
+ private:
+  static uint64_t mask(int l) { return l >= 64 ? ~uint64_t(0) : (uint64_t(1) << l) - 1; }
+  void send(uint64_t *d, const uint64_t *corr, int n, int l, uint64_t p) {
+    std::vector<uint64_t> x(n), c(corr, corr + n);
+    for (int i = 0; i < n; ++i) x[i] = p ? rng_() % p : rng_() & mask(l);
+    std::copy(x.begin(), x.end(), d);
+    std::lock_guard<std::mutex> g(box_->m);
+    box_->q.emplace_back(std::move(x), std::move(c));
+    box_->cv.notify_all();
+  }
+  void recv(uint64_t *d, const bool *b, int n, int l, uint64_t p) {
+    std::unique_lock<std::mutex> g(box_->m);
+    box_->cv.wait(g, [&] { return !box_->q.empty(); });
+    auto msg = std::move(box_->q.front());
+    box_->q.pop_front();
+    g.unlock();
+    for (int i = 0; i < n; ++i) {
+      if (p) d[i] = (uint64_t)(((unsigned __int128)msg.first[i] + (b[i] ? msg.second[i] % p : 0)) % p);
+      else d[i] = (msg.first[i] + (b[i] ? msg.second[i] : 0)) & mask(l);
+    }
+  }
+  std::shared_ptr<Mailbox> box_;
+  std::mt19937_64 rng_;
+};
+
+}  // namespace mm

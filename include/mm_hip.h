@@ -175,6 +175,28 @@ int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint6
 int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals, void *stream);
 
 /* =====================================================================================
+ * Randomness on the device.  The reference samples through SEAL's UniformRandomGenerator
+ * (Blake2xb): parms.random_generator()->create() at hom_conv2d_ss.cc:759-760, hom_bn_ss.cc:329.
+ * Here a ChaCha20 keystream (RFC 8439 block function; block counter in words 12-13, stream id in
+ * words 14-15) keyed by the caller feeds the same three distributions.  Streams are not
+ * comparable with SEAL's, only the distributions are; parity tests inject explicit randomness.
+ * ===================================================================================== */
+/* raw keystream as little-endian 64-bit words, starting at block `counter0` */
+int mmh_chacha20_words(const uint32_t key[8], uint64_t stream_id, uint64_t counter0, uint64_t *d_out,
+                       size_t n_words, void *stream);
+/* seal::util::sample_poly_ternary (hom_conv2d_ss.cc:302): n_coeffs values in {-1,0,1} */
+int mmh_sample_ternary(const uint32_t key[8], uint64_t stream_id, int64_t *d_out, size_t n_coeffs, void *stream);
+/* SEAL_NOISE_SAMPLER = sample_poly_cbd (hom_conv2d_ss.cc:329): popcount(21 bits) - popcount(21 bits) */
+int mmh_sample_noise(const uint32_t key[8], uint64_t stream_id, int64_t *d_out, size_t n_coeffs, void *stream);
+/* seal::util::sample_poly_uniform (hom_conv2d_ss.cc:206): [n_polys][limbs(lv)][N], limb l < q_l */
+int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key[8], uint64_t stream_id, uint64_t *d_out,
+                       size_t n_polys, void *stream);
+/* signed small polynomials [n][N] -> RNS + forward NTT [n][limbs][N]: secret key to NTT form
+ * (seal::KeyGenerator, cheetah-api.cpp:109-111) */
+int mmh_signed_to_ntt(const mmh_ctx *ctx, int lv, const int64_t *d_signed, size_t n, uint64_t *d_out,
+                      void *stream);
+
+/* =====================================================================================
  * HomConv2DSS (include/gemini/cheetah/hom_conv2d_ss.h:27-115) as layer-level calls.
  * A plan fixes the geometry of one layer (HomConv2DSS::Meta: ishape, fshape, n_filters,
  * padding, stride, is_shared_input) and owns the device index tables derived from

@@ -6,4 +6,4 @@ library, moves buffers with torch, and mirrors the reference's operator names.
 There is no CPU fallback: importing :mod:`openmm_amd.lib` without the built library
 raises.
 """
-from .lib import MMHError, Context, load_library  # noqa: F401
+from .lib import MMHError, Context, Sampler, load_library  # noqa: F401

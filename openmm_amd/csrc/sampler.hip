@@ -1,0 +1,147 @@
+// Device-side randomness: ChaCha20 keystream (RFC 8439 block function, 64-bit block counter in
+// words 12-13, 64-bit stream id in words 14-15) and the three distributions the path draws from:
+// uniform mod q (seal::util::sample_poly_uniform, hom_conv2d_ss.cc:206), ternary
+// (sample_poly_ternary, :302) and centred binomial noise (SEAL_NOISE_SAMPLER, :329; SEAL's
+// sample_poly_cbd: popcount of 21 bits minus popcount of 21 bits).  The reference draws from
+// SEAL's Blake2xb generator; streams are not comparable across implementations, only the
+// distributions are, and every consumer of randomness in this library takes it as an argument.
+#include "common.hpp"
+
+namespace mmh {
+struct ChaChaKey {
+  u32 k[8];
+};
+
+__device__ __forceinline__ u32 rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+#define MMH_QR(a, b, c, d) \
+  a += b; d ^= a; d = rotl32(d, 16); \
+  c += d; b ^= c; b = rotl32(b, 12); \
+  a += b; d ^= a; d = rotl32(d, 8);  \
+  c += d; b ^= c; b = rotl32(b, 7);
+
+// one 64-byte block as 8 little-endian u64 words
+__device__ __forceinline__ void chacha20_block(const ChaChaKey &key, u64 stream_id, u64 counter, u64 out[8]) {
+  const u32 in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                      key.k[4], key.k[5], key.k[6], key.k[7], (u32)counter, (u32)(counter >> 32), (u32)stream_id,
+                      (u32)(stream_id >> 32)};
+  u32 x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = in[i];
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    MMH_QR(x[0], x[4], x[8], x[12]) MMH_QR(x[1], x[5], x[9], x[13]) MMH_QR(x[2], x[6], x[10], x[14])
+    MMH_QR(x[3], x[7], x[11], x[15]) MMH_QR(x[0], x[5], x[10], x[15]) MMH_QR(x[1], x[6], x[11], x[12])
+    MMH_QR(x[2], x[7], x[8], x[13]) MMH_QR(x[3], x[4], x[9], x[14])
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (u64)(x[2 * i] + in[2 * i]) | ((u64)(x[2 * i + 1] + in[2 * i + 1]) << 32);
+}
+
+// MODE 0: raw words; 1: ternary in {-1,0,1}; 2: centred binomial (21 - 21 bits)
+template <int MODE>
+__global__ __launch_bounds__(256) void sample_words_kernel(ChaChaKey key, u64 stream_id, u64 counter0, u64 *out,
+                                                           size_t n_words) {
+  const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (blk * 8 >= n_words) return;
+  u64 w[8];
+  chacha20_block(key, stream_id, counter0 + blk, w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t idx = blk * 8 + i;
+    if (idx >= n_words) break;
+    u64 v = w[i];
+    if (MODE == 1) v = (u64)((int64_t)mulhi64(v, 3) - 1);
+    if (MODE == 2) v = (u64)((int64_t)__popcll(v & 0x1FFFFF) - (int64_t)__popcll((v >> 21) & 0x1FFFFF));
+    out[idx] = v;
+  }
+}
+
+// uniform in [0, q_l): 128 keystream bits reduced mod q_l (statistical distance < 2^-64)
+__global__ __launch_bounds__(256) void sample_uniform_kernel(ChaChaKey key, u64 stream_id, u64 counter0, u64 *out,
+                                                             size_t total, int logN, int limbs,
+                                                             const DevMod *__restrict__ mods) {
+  const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;  // 4 coefficients per block
+  if (blk * 4 >= total) return;
+  u64 w[8];
+  chacha20_block(key, stream_id, counter0 + blk, w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t idx = blk * 4 + i;
+    if (idx >= total) break;
+    const DevMod &q = mods[(idx >> logN) % limbs];
+    // (hi*2^64 + lo) mod q with hi reduced first so that Barrett's quotient fits 64 bits
+    const u64 hi = reduce64(w[2 * i + 1], q);
+    out[idx] = csub(barrett128(hi, w[2 * i], q.q, q.barrett_hi, q.barrett_lo), q.q);
+  }
+}
+
+__global__ __launch_bounds__(256) void signed_to_rns_kernel2(const int64_t *__restrict__ v, u64 *__restrict__ out,
+                                                             size_t total, int logN, int limbs,
+                                                             const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const int64_t x = v[idx];
+  for (int l = 0; l < limbs; ++l) {
+    const u64 q = mods[l].q;
+    out[((k * limbs + l) << logN) + i] = x >= 0 ? (u64)x : q - (u64)(-x);
+  }
+}
+int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs, int mod_base,
+                 hipStream_t s);
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+}  // namespace mmh
+
+using namespace mmh;
+
+static int sample_words(int mode, const uint32_t key[8], uint64_t stream_id, uint64_t counter0, uint64_t *d_out,
+                        size_t n_words, void *stream) {
+  MMH_REQUIRE(key && (d_out || n_words == 0), MMH_ERR_NULL_POINTER);
+  if (n_words == 0) return MMH_OK;
+  ChaChaKey k;
+  for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+  const size_t blocks = (n_words + 7) / 8;
+  auto kern = mode == 0 ? sample_words_kernel<0> : (mode == 1 ? sample_words_kernel<1> : sample_words_kernel<2>);
+  hipLaunchKernelGGL(kern, dim3(nblk(blocks)), dim3(256), 0, (hipStream_t)stream, k, stream_id, counter0, d_out,
+                     n_words);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_chacha20_words(const uint32_t key[8], uint64_t stream_id, uint64_t counter0, uint64_t *d_out,
+                                  size_t n_words, void *stream) {
+  return sample_words(0, key, stream_id, counter0, d_out, n_words, stream);
+}
+extern "C" int mmh_sample_ternary(const uint32_t key[8], uint64_t stream_id, int64_t *d_out, size_t n_coeffs,
+                                  void *stream) {
+  return sample_words(1, key, stream_id, 0, (uint64_t *)d_out, n_coeffs, stream);
+}
+extern "C" int mmh_sample_noise(const uint32_t key[8], uint64_t stream_id, int64_t *d_out, size_t n_coeffs,
+                                void *stream) {
+  return sample_words(2, key, stream_id, 0, (uint64_t *)d_out, n_coeffs, stream);
+}
+extern "C" int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key[8], uint64_t stream_id,
+                                  uint64_t *d_out, size_t n_polys, void *stream) {
+  MMH_REQUIRE(ctx && key && (d_out || n_polys == 0), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(lv == 0 || lv == 1, MMH_ERR_INVALID_ARG);
+  if (n_polys == 0) return MMH_OK;
+  ChaChaKey k;
+  for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+  const int limbs = lv == 0 ? (int)ctx->L : 1;
+  const size_t total = n_polys * limbs * ctx->N;
+  hipLaunchKernelGGL(sample_uniform_kernel, dim3(nblk((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k,
+                     stream_id, (u64)0, d_out, total, ctx->logN, limbs, ctx->d_mods);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+extern "C" int mmh_signed_to_ntt(const mmh_ctx *ctx, int lv, const int64_t *d_signed, size_t n, uint64_t *d_out,
+                                 void *stream) {
+  MMH_REQUIRE(ctx && (n == 0 || (d_signed && d_out)), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(lv == 0 || lv == 1, MMH_ERR_INVALID_ARG);
+  if (n == 0) return MMH_OK;
+  const int limbs = lv == 0 ? (int)ctx->L : 1;
+  hipLaunchKernelGGL(signed_to_rns_kernel2, dim3(nblk(n * ctx->N)), dim3(256), 0, (hipStream_t)stream, d_signed,
+                     d_out, n * ctx->N, ctx->logN, limbs, ctx->d_mods);
+  MMH_HIP(hipGetLastError());
+  return ntt_dispatch(ctx, false, d_out, n, limbs, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,375 @@
+// gemini::CheetahLinear on libmm_hip (C ABI only: no HIP, no SEAL in this file).
+// Choreography follows SCI/src/cheetah/cheetah-api.cpp: keys and pk exchange :73-197, fc :298-375,
+// conv2d :377-446, bn :527-603, BOLE :605-650.
+#include "mm_gemini/cheetah_linear.h"
+
+#include <cmath>
+#include <cstdio>
+#include <map>
+
+#include "mm_hip.h"
+
+namespace gemini {
+
+std::string CodeMessage(Code code) {  // include/gemini/core/types.cc:3-24
+  switch (code) {
+    case Code::OK: return "ok";
+    case Code::ERR_CONFIG: return "Error: configuration";
+    case Code::ERR_NULL_POINTER: return "Error: null pointer";
+    case Code::ERR_DIM_MISMATCH: return "Error: dimension mismatch";
+    case Code::ERR_SEAL_MEMORY: return "Error: memory allocation";
+    case Code::ERR_OUT_BOUND: return "Error: out-of-bound";
+    case Code::ERR_INVALID_ARG: return "Error: invalid arguments";
+    case Code::ERR_INTERNAL: return "Error: internal error";
+    default: return "Unknown code";
+  }
+}
+
+namespace {
+const int kAlice = 1, kBob = 2;
+// SCI/src/utils/constants.h:45-50
+const std::map<int, uint64_t> kFieldPrimes{{32, 4293918721ULL},   {33, 8585084929ULL},   {34, 17171218433ULL},
+                                           {35, 34359214081ULL},  {36, 68686184449ULL},  {37, 137438822401ULL},
+                                           {38, 274824036353ULL}, {39, 549753716737ULL}, {40, 1099480956929ULL},
+                                           {41, 2198100901889ULL}};
+
+void must(int rc, const char *what) {
+  if (rc != MMH_OK)
+    throw std::runtime_error(std::string(what) + " [" + CodeMessage(static_cast<Code>(rc)) + "] " + mmh_last_error());
+}
+
+// device buffer of 64-bit words
+struct Dev {
+  uint64_t *p = nullptr;
+  size_t n = 0;
+  Dev() = default;
+  explicit Dev(size_t words) { alloc(words); }
+  Dev(const Dev &) = delete;
+  Dev(Dev &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
+  ~Dev() { mmh_free(p); }
+  void alloc(size_t words) {
+    mmh_free(p);
+    p = nullptr;
+    n = words;
+    void *q = nullptr;
+    must(mmh_malloc(&q, (words ? words : 1) * 8), "mmh_malloc");
+    p = static_cast<uint64_t *>(q);
+  }
+  void upload(const uint64_t *src, size_t words) {
+    must(mmh_memcpy_h2d(p, src, words * 8, nullptr), "h2d");
+    must(mmh_stream_sync(nullptr), "sync");
+  }
+  void download(uint64_t *dst, size_t words) const {
+    must(mmh_memcpy_d2h(dst, p, words * 8, nullptr), "d2h");
+    must(mmh_stream_sync(nullptr), "sync");
+  }
+};
+
+struct Keys {  // one BFV context with the party's key material on the device
+  mmh_ctx *ctx = nullptr;
+  Dev sk, pk, pk_last, sk_last;  // sk [L][N] (BOB), pk [2][L][N] (ALICE), restrictions to the last level
+};
+}  // namespace
+
+struct CheetahLinear::Impl {
+  static constexpr size_t N = 4096, L = 2;
+  Keys ring, field;
+  uint32_t key[8];
+  mutable uint64_t stream_id = 1;
+  mm::IOChannel *io = nullptr;
+
+  ~Impl() {
+    mmh_ctx_destroy(ring.ctx);
+    mmh_ctx_destroy(field.ctx);
+  }
+  uint64_t sid() const { return stream_id++; }
+
+  // ---- randomness (device ChaCha20 keyed from the OS) ----
+  Dev uniform(const mmh_ctx *c, int lv, size_t n) const {
+    Dev d(n * (lv == 0 ? L : 1) * N);
+    must(mmh_sample_uniform(c, lv, key, sid(), d.p, n, nullptr), "sample_uniform");
+    return d;
+  }
+  Dev ternary(size_t n) const {
+    Dev d(n * N);
+    must(mmh_sample_ternary(key, sid(), (int64_t *)d.p, n * N, nullptr), "sample_ternary");
+    return d;
+  }
+  Dev noise(size_t n) const {
+    Dev d(n * N);
+    must(mmh_sample_noise(key, sid(), (int64_t *)d.p, n * N, nullptr), "sample_noise");
+    return d;
+  }
+  Dev words(size_t n) const {
+    Dev d(n);
+    must(mmh_chacha20_words(key, sid(), 0, d.p, n, nullptr), "chacha20");
+    return d;
+  }
+
+  // ---- keys: BOB generates and sends pk, ALICE receives (cheetah-api.cpp:107-141, :164-196) ----
+  void setup_keys(Keys &k, int party) {
+    std::vector<uint64_t> host(2 * L * N);
+    k.pk.alloc(2 * L * N);
+    k.pk_last.alloc(2 * N);
+    if (party == kBob) {
+      k.sk.alloc(L * N);
+      k.sk_last.alloc(N);
+      Dev s = ternary(1), a = uniform(k.ctx, 0, 1), e = noise(1);
+      must(mmh_signed_to_ntt(k.ctx, 0, (const int64_t *)s.p, 1, k.sk.p, nullptr), "keygen");
+      must(mmh_make_public_key(k.ctx, k.sk.p, a.p, (const int64_t *)e.p, k.pk.p, nullptr), "create_public_key");
+      k.pk.download(host.data(), host.size());
+      std::vector<uint64_t> skh(L * N);
+      k.sk.download(skh.data(), skh.size());
+      k.sk_last.upload(skh.data(), N);
+      uint64_t sz = host.size() * 8;
+      io->send_data(&sz, sizeof(sz));
+      io->send_data(host.data(), sz);
+      io->flush();
+    } else {
+      uint64_t sz = 0;
+      io->recv_data(&sz, sizeof(sz));
+      if (sz != host.size() * 8) throw std::runtime_error("CheetahLinear: public key size mismatch");
+      io->recv_data(host.data(), sz);
+      k.pk.upload(host.data(), host.size());
+    }
+    // pk restricted to the last level {q0}: limb 0 of both polynomials
+    std::vector<uint64_t> last(2 * N);
+    std::copy(host.begin(), host.begin() + N, last.begin());
+    std::copy(host.begin() + L * N, host.begin() + L * N + N, last.begin() + N);
+    k.pk_last.upload(last.data(), last.size());
+  }
+
+  // ---- ciphertext transport: u32 count, then the raw coefficient words (cheetah-api.cpp:11-29) ----
+  void send_cts(const Dev &d, size_t n_cts, size_t words_per_ct) const {
+    std::vector<uint64_t> host(n_cts * words_per_ct);
+    d.download(host.data(), host.size());
+    uint32_t n = (uint32_t)n_cts;
+    io->send_data(&n, sizeof(n));
+    io->send_data(host.data(), host.size() * 8);
+    io->flush();
+  }
+  Dev recv_cts(size_t expect, size_t words_per_ct) const {
+    uint32_t n = 0;
+    io->recv_data(&n, sizeof(n));
+    if (n != expect) throw std::runtime_error("CheetahLinear: ciphertext count mismatch");
+    std::vector<uint64_t> host((size_t)n * words_per_ct);
+    io->recv_data(host.data(), host.size() * 8);
+    Dev d(host.size());
+    d.upload(host.data(), host.size());
+    return d;
+  }
+};
+
+CheetahLinear::CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, size_t /*nthreads*/, int device)
+    : party_(party), io_(io), base_mod_(base_mod), impl_(new Impl()) {
+  if (base_mod < 2ULL || (int)std::log2(base_mod) >= 45)  // cheetah-api.cpp:76-78
+    throw std::logic_error("CheetahLinear: base_mod out-of-bound [2, 2^45)");
+  if (party != kAlice && party != kBob) throw std::invalid_argument("CheetahLinear: party");
+  impl_->io = io;
+  FILE *f = std::fopen("/dev/urandom", "rb");
+  if (!f || std::fread(impl_->key, 1, sizeof(impl_->key), f) != sizeof(impl_->key)) {
+    if (f) std::fclose(f);
+    throw std::runtime_error("CheetahLinear: cannot seed the sampler");
+  }
+  std::fclose(f);
+  const int bits[2] = {60, 49};  // :99-103
+  must(mmh_ctx_create_bits(&impl_->ring.ctx, Impl::N, bits, 2, base_mod, device), "SEALContext");
+  impl_->setup_keys(impl_->ring, party);
+  const bool is_mod_2k = (base_mod & (base_mod - 1)) == 0;
+  if (!is_mod_2k) throw std::runtime_error("Not implemented yet.");  // :143-147
+  field_mod_ = kFieldPrimes.at((int)std::log2(base_mod));            // setUpForBN :153
+  must(mmh_ctx_create_bits(&impl_->field.ctx, Impl::N, bits, 2, field_mod_, device), "SEALContext (SIMD)");
+  impl_->setup_keys(impl_->field, party);
+}
+
+CheetahLinear::~CheetahLinear() = default;
+
+void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<Tensor<uint64_t>> &filters,
+                           const ConvMeta &meta, Tensor<uint64_t> &out_tensor) const {
+  if (!meta.ishape.IsSameSize(in_tensor.shape())) throw std::invalid_argument("CheetahLinear::conv2d meta.ishape mismatch");
+  if (meta.n_filters != filters.size()) throw std::invalid_argument("CheetahLinear::conv2d meta.n_filters mismatch");
+  for (const auto &f : filters)
+    if (!meta.fshape.IsSameSize(f.shape())) throw std::invalid_argument("CheetahLinear::conv2d meta.fshape mismatch");
+  const Impl &I = *impl_;
+  const size_t N = Impl::N, L = Impl::L;
+  mmh_conv_meta m{meta.ishape.channels(), meta.ishape.height(), meta.ishape.width(), meta.fshape.height(),
+                  meta.fshape.width(), (int64_t)meta.n_filters, meta.padding == Padding::SAME, (int32_t)meta.stride,
+                  meta.is_shared_input};
+  mmh_conv_plan *plan = nullptr;
+  must(mmh_conv_plan_create(I.ring.ctx, &m, &plan), "CheetahLinear::conv2d shape inference");
+  struct Guard { mmh_conv_plan *p; ~Guard() { mmh_conv_plan_destroy(p); } } guard{plan};
+  size_t n_in, n_cs, n_sp, n_out;
+  int64_t oshape[3];
+  must(mmh_conv_plan_info(plan, &n_in, &n_cs, &n_sp, &n_out, oshape, nullptr), "plan_info");
+  TensorShape out_shape({oshape[0], oshape[1], oshape[2]});
+  if (!out_tensor.shape().IsSameSize(out_shape)) out_tensor.Reshape(out_shape);
+  const size_t img_words = (size_t)meta.ishape.num_elements(), out_words = (size_t)out_shape.num_elements();
+  Dev img(img_words);
+  img.upload(in_tensor.data(), img_words);
+  if (party_ == kBob) {
+    Dev a = I.uniform(I.ring.ctx, 0, n_in), e = I.noise(n_in), cts(n_in * 2 * L * N);
+    must(mmh_conv_encrypt_image(plan, I.ring.sk.p, img.p, a.p, (const int64_t *)e.p, cts.p, nullptr),
+         "CheetahLinear::conv2d encryptImage");
+    I.send_cts(cts, n_in, 2 * L * N);
+    Dev res = I.recv_cts(n_out, 2 * N), out(out_words);
+    must(mmh_conv_decrypt(plan, I.ring.sk_last.p, res.p, out.p, nullptr), "CheetahLinear::conv2d decryptToTensor");
+    out.download(out_tensor.data(), out_words);
+  } else {
+    const size_t f_words = (size_t)meta.fshape.num_elements();
+    std::vector<uint64_t> fh(meta.n_filters * f_words);
+    for (size_t k = 0; k < filters.size(); ++k) std::copy(filters[k].data(), filters[k].data() + f_words, fh.begin() + k * f_words);
+    // conv2DOneFilter (hom_conv2d_ss.cc:573-580): an all-zero filter is an error (values are mod base_mod)
+    for (size_t k = 0; k < filters.size(); ++k) {
+      bool nz = false;
+      for (size_t i = 0; i < f_words && !nz; ++i) nz = (fh[k * f_words + i] % base_mod_) != 0;
+      if (!nz) throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
+    }
+    Dev dfilt(fh.size()), fpts(meta.n_filters * n_cs * N), spts;
+    dfilt.upload(fh.data(), fh.size());
+    must(mmh_conv_encode_filters(plan, dfilt.p, fpts.p, nullptr), "CheetahLinear::conv2d ecnodeFilters");
+    if (meta.is_shared_input) {
+      spts.alloc(n_in * N);
+      must(mmh_conv_encode_image(plan, img.p, spts.p, nullptr), "CheetahLinear::conv2d encodeImage");
+    }
+    Dev cts = I.recv_cts(n_in, 2 * L * N);
+    Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
+    Dev out_cts(n_out * 2 * N), share(out_words);
+    must(mmh_conv_server(plan, cts.p, spts.p, fpts.p, I.ring.pk_last.p, (const int64_t *)u.p, (const int64_t *)e1.p,
+                         mask.p, out_cts.p, share.p, nullptr),
+         "CheetahLinear::conv2d conv2DSS:");
+    share.download(out_tensor.data(), out_words);
+    I.send_cts(out_cts, n_out, 2 * N);
+  }
+}
+
+void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
+                       Tensor<uint64_t> &out_vec_share) const {
+  if (!input_vector.shape().IsSameSize(meta.input_shape)) throw std::invalid_argument("CheetahLinear::fc input shape mismatch");
+  if (party_ == kAlice && !weight_matrix.shape().IsSameSize(meta.weight_shape))
+    throw std::invalid_argument("CheetahLinear::fc weight shape mismatch");
+  TensorShape out_shape({meta.weight_shape.dim_size(0)});
+  if (!out_vec_share.shape().IsSameSize(out_shape)) out_vec_share.Reshape(out_shape);
+  const Impl &I = *impl_;
+  const size_t N = Impl::N, L = Impl::L;
+  mmh_fc_meta m{meta.weight_shape.rows(), meta.weight_shape.cols(), meta.is_shared_input};
+  mmh_fc_plan *plan = nullptr;
+  must(mmh_fc_plan_create(I.ring.ctx, &m, &plan), "CheetahLinear::fc getSplit");
+  struct Guard { mmh_fc_plan *p; ~Guard() { mmh_fc_plan_destroy(p); } } guard{plan};
+  size_t n_in, n_out;
+  must(mmh_fc_plan_info(plan, nullptr, &n_in, &n_out), "plan_info");
+  const size_t rows = (size_t)m.rows, cols = (size_t)m.cols;
+  Dev vec(cols);
+  vec.upload(input_vector.data(), cols);
+  if (party_ == kBob) {
+    Dev a = I.uniform(I.ring.ctx, 0, n_in), e = I.noise(n_in), cts(n_in * 2 * L * N);
+    must(mmh_fc_encrypt_input(plan, I.ring.sk.p, vec.p, a.p, (const int64_t *)e.p, cts.p, nullptr),
+         "CheetahLinear::fc encryptInputVector");
+    I.send_cts(cts, n_in, 2 * L * N);
+    Dev res = I.recv_cts(n_out, 2 * N), out(rows);
+    must(mmh_fc_decrypt(plan, I.ring.sk_last.p, res.p, out.p, nullptr), "CheetahLinear::fc decryptToVector");
+    out.download(out_vec_share.data(), rows);
+  } else {
+    Dev w(rows * cols), wpts(n_out * n_in * N), spts;
+    w.upload(weight_matrix.data(), rows * cols);
+    must(mmh_fc_encode_weights(plan, w.p, wpts.p, nullptr), "CheetahLinear::fc encodeWeightMatrix error");
+    {  // matVecMul rejects a sub-matrix that encodes to zero (hom_fc_ss.cc:414-422)
+      int64_t split[2];
+      must(mmh_fc_plan_info(plan, split, nullptr, nullptr), "plan_info");
+      for (size_t rb = 0; rb < n_out; ++rb)
+        for (size_t cb = 0; cb < n_in; ++cb) {
+          bool nz = false;
+          for (size_t r = rb * split[0]; r < std::min<size_t>((rb + 1) * split[0], rows) && !nz; ++r)
+            for (size_t c = cb * split[1]; c < std::min<size_t>((cb + 1) * split[1], cols) && !nz; ++c)
+              nz = (weight_matrix.data()[r * cols + c] % base_mod_) != 0;
+          if (!nz) throw std::runtime_error("CheetahLinear::fc matmul2D error [" + CodeMessage(Code::ERR_INVALID_ARG) + "]");
+        }
+    }
+    if (meta.is_shared_input) {
+      spts.alloc(n_in * N);
+      must(mmh_fc_encode_input(plan, vec.p, spts.p, nullptr), "CheetahLinear::fc encodeInputVector error");
+    }
+    Dev cts = I.recv_cts(n_in, 2 * L * N);
+    Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
+    Dev out_cts(n_out * 2 * N), share(rows);
+    must(mmh_fc_server(plan, cts.p, spts.p, wpts.p, I.ring.pk_last.p, (const int64_t *)u.p, (const int64_t *)e1.p, mask.p,
+                       out_cts.p, share.p, nullptr),
+         "CheetahLinear::fc matmul2D error");
+    share.download(out_vec_share.data(), rows);
+    I.send_cts(out_cts, n_out, 2 * N);
+  }
+}
+
+void CheetahLinear::bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &scale_vector, const BNMeta &meta,
+                       Tensor<uint64_t> &out_vector) const {
+  if (meta.is_shared_input && !input_vector.shape().IsSameSize(meta.vec_shape))
+    throw std::runtime_error("bn input_vector shape mismatch");
+  if (meta.target_base_mod != field_mod_)
+    throw std::runtime_error("bn encryptVector [" + CodeMessage(Code::ERR_OUT_BOUND) + "]");  // hom_bn_ss.cc:156
+  const Impl &I = *impl_;
+  const size_t N = Impl::N, L = Impl::L, n = (size_t)meta.vec_shape.length();
+  const size_t n_ct = (n + std::min(n, N) - 1) / std::min(n, N);
+  if (!out_vector.shape().IsSameSize(meta.vec_shape)) out_vector.Reshape(meta.vec_shape);
+  if (party_ == kBob) {
+    Dev vec(n), a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct), cts(n_ct * 2 * L * N);
+    vec.upload(input_vector.data(), n);
+    must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, vec.p, n, a.p, (const int64_t *)e.p, cts.p, nullptr),
+         "bn encryptVector");
+    I.send_cts(cts, n_ct, 2 * L * N);
+    Dev res = I.recv_cts(n_ct, 2 * N), out(n);
+    must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, nullptr), "bn decryptToVector");
+    out.download(out_vector.data(), n);
+  } else {
+    if (!scale_vector.shape().IsSameSize(meta.vec_shape)) throw std::runtime_error("bn scale_vector shape mismatch");
+    Dev scale(n), sc_pts(n_ct * N), in_pts;
+    scale.upload(scale_vector.data(), n);
+    must(mmh_bn_encode_vector(I.field.ctx, scale.p, n, sc_pts.p, nullptr), "bn encodeScales");
+    if (meta.is_shared_input) {
+      Dev vec(n);
+      vec.upload(input_vector.data(), n);
+      in_pts.alloc(n_ct * N);
+      must(mmh_bn_encode_vector(I.field.ctx, vec.p, n, in_pts.p, nullptr), "bn encodeVector");
+    }
+    Dev cts = I.recv_cts(n_ct, 2 * L * N), rnd = I.words(n), out_cts(n_ct * 2 * N), share(n);
+    must(mmh_bn_server(I.field.ctx, cts.p, in_pts.p, sc_pts.p, n, rnd.p, out_cts.p, share.p, nullptr), "bn failed");
+    share.download(out_vector.data(), n);
+    I.send_cts(out_cts, n_ct, 2 * N);
+  }
+}
+
+void CheetahLinear::BOLE(const Tensor<uint64_t> &x, const Tensor<uint64_t> &y, const BNMeta &meta,
+                         Tensor<uint64_t> &out_vector) const {
+  if (!x.shape().IsSameSize(meta.vec_shape) || !y.shape().IsSameSize(meta.vec_shape))
+    throw std::runtime_error("BOLE input_vector shape mismatch");
+  if (meta.target_base_mod != field_mod_) throw std::runtime_error("BOLE [" + CodeMessage(Code::ERR_OUT_BOUND) + "]");
+  const Impl &I = *impl_;
+  const size_t N = Impl::N, L = Impl::L, n = (size_t)meta.vec_shape.length();
+  const size_t n_ct = (n + std::min(n, N) - 1) / std::min(n, N), ct_words = 2 * L * N;
+  if (!out_vector.shape().IsSameSize(meta.vec_shape)) out_vector.Reshape(meta.vec_shape);
+  Dev dx(n), dy(n), out(n);
+  dx.upload(x.data(), n);
+  dy.upload(y.data(), n);
+  if (party_ == kBob) {
+    Dev cts(2 * n_ct * ct_words);
+    for (int k = 0; k < 2; ++k) {  // encryptVector(x), encryptVector(y)  (cheetah-api.cpp:617-621)
+      Dev a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct);
+      must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, k ? dy.p : dx.p, n, a.p, (const int64_t *)e.p,
+                                 cts.p + k * n_ct * ct_words, nullptr),
+           "BOLE encryptVector");
+    }
+    I.send_cts(cts, 2 * n_ct, ct_words);
+    Dev res = I.recv_cts(n_ct, 2 * N);
+    must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, nullptr), "BOLE decryptToVector");
+  } else {
+    Dev pts(2 * n_ct * N);  // [py ; px]
+    must(mmh_bn_encode_vector(I.field.ctx, dy.p, n, pts.p, nullptr), "BOLE encodeVector");
+    must(mmh_bn_encode_vector(I.field.ctx, dx.p, n, pts.p + n_ct * N, nullptr), "BOLE encodeVector");
+    Dev cts = I.recv_cts(2 * n_ct, ct_words), rnd = I.words(n), out_cts(n_ct * 2 * N);
+    must(mmh_bole_server(I.field.ctx, cts.p, pts.p, n, rnd.p, out_cts.p, out.p, nullptr), "BOLE bole");
+    I.send_cts(out_cts, n_ct, 2 * N);
+  }
+  // local cross term x_i * y_i on both sides (cheetah-api.cpp:648-649)
+  must(mmh_bole_cross_term(out.p, dx.p, dy.p, n, field_mod_, nullptr), "BOLE cross term");
+  out.download(out_vector.data(), n);
+}
+
+}  // namespace gemini

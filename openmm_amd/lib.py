@@ -57,6 +57,11 @@ SIGNATURES = {
     "mmh_truncate_and_zero": [_vp, _vp, _sz, _vp, _sz, _vp],
     "mmh_batch_encode": [_vp, _vp, _sz, _vp, _vp],
     "mmh_batch_decode": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_chacha20_words": [C.POINTER(C.c_uint32), _u64, _u64, _vp, _sz, _vp],
+    "mmh_sample_ternary": [C.POINTER(C.c_uint32), _u64, _vp, _sz, _vp],
+    "mmh_sample_noise": [C.POINTER(C.c_uint32), _u64, _vp, _sz, _vp],
+    "mmh_sample_uniform": [_vp, _int, C.POINTER(C.c_uint32), _u64, _vp, _sz, _vp],
+    "mmh_signed_to_ntt": [_vp, _int, _vp, _sz, _vp, _vp],
     "mmh_conv_plan_create": [_vp, _vp, C.POINTER(_vp)],
     "mmh_conv_plan_destroy": [_vp],
     "mmh_conv_plan_info": [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz),
@@ -290,3 +295,48 @@ class Context:
         check(self.lib.mmh_batch_decode(self.handle, dptr(pts), pts.numel() // self.N, dptr(out),
                                         _stream_ptr()))
         return out
+
+
+class Sampler:
+    """ChaCha20-keyed device sampler: every call consumes a fresh stream id."""
+
+    def __init__(self, ctx, key=None):
+        self.ctx = ctx
+        key = os.urandom(32) if key is None else key
+        assert len(key) == 32
+        self.key = (C.c_uint32 * 8).from_buffer_copy(key)
+        self.next_stream = 1
+
+    def _sid(self):
+        s = self.next_stream
+        self.next_stream += 1
+        return s
+
+    def words(self, n):
+        out = self.ctx._empty(n)
+        check(self.ctx.lib.mmh_chacha20_words(self.key, self._sid(), 0, dptr(out), n, _stream_ptr()))
+        return out
+
+    def ternary(self, n_polys):
+        out = self.ctx._empty(n_polys, self.ctx.N)
+        check(self.ctx.lib.mmh_sample_ternary(self.key, self._sid(), dptr(out), out.numel(), _stream_ptr()))
+        return out
+
+    def noise(self, n_polys):
+        out = self.ctx._empty(n_polys, self.ctx.N)
+        check(self.ctx.lib.mmh_sample_noise(self.key, self._sid(), dptr(out), out.numel(), _stream_ptr()))
+        return out
+
+    def uniform(self, n_polys, lv=0):
+        out = self.ctx._empty(n_polys, self.ctx.limbs(lv), self.ctx.N)
+        check(self.ctx.lib.mmh_sample_uniform(self.ctx.handle, lv, self.key, self._sid(), dptr(out), n_polys,
+                                              _stream_ptr()))
+        return out
+
+    def keygen(self):
+        """KeyGenerator: ternary secret (NTT form) and pk = (-(a s + e), a) (cheetah-api.cpp:107-114)"""
+        s = self.ternary(1)
+        sk = self.ctx._empty(self.ctx.L, self.ctx.N)
+        check(self.ctx.lib.mmh_signed_to_ntt(self.ctx.handle, 0, dptr(s), 1, dptr(sk), _stream_ptr()))
+        pk = self.ctx.make_public_key(sk, self.uniform(1)[0].contiguous(), self.noise(1)[0].contiguous())
+        return sk, pk

@@ -1,0 +1,236 @@
+// Two-party loop-back acceptance tests of the C++ host mirror, modelled on the reference's
+// tests/{bole,ring_to_field,field_to_ring,ring_extension}_test.cpp: both parties run in one
+// process (two threads) over LoopbackIO and an ideal COT, draw random inputs, run the protocol,
+// reconstruct and compare with cleartext arithmetic.
+//   usage: loopback_test [log2(n) for the vector tests, default 16] [full=0|1: ResNet50 3x3 layer]
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <random>
+#include <thread>
+
+#include "mm_gemini/cheetah_linear.h"
+#include "mm_gemini/truncation.h"
+
+using gemini::CheetahLinear;
+using gemini::Padding;
+using gemini::Tensor;
+using gemini::TensorShape;
+using u64 = uint64_t;
+
+static int g_fail = 0;
+#define EXPECT(cond, name)                                  \
+  do {                                                      \
+    if (cond) std::printf("PASS %s\n", name);               \
+    else { std::printf("FAIL %s\n", name); ++g_fail; }      \
+  } while (0)
+
+struct Party {
+  int id;
+  std::unique_ptr<mm::LoopbackIO> io;
+  std::unique_ptr<mm::IdealCOT> cot;
+  std::unique_ptr<CheetahLinear> linear;
+  std::unique_ptr<mm::Truncation> trunc;
+};
+
+static void both(Party &a, Party &b, const std::function<void(Party &)> &fn) {
+  std::exception_ptr ea, eb;
+  std::thread ta([&] { try { fn(a); } catch (...) { ea = std::current_exception(); } });
+  std::thread tb([&] { try { fn(b); } catch (...) { eb = std::current_exception(); } });
+  ta.join();
+  tb.join();
+  if (ea) std::rethrow_exception(ea);
+  if (eb) std::rethrow_exception(eb);
+}
+
+static int64_t to_signed(u64 v, int bw) {
+  const u64 mask = bw == 64 ? ~0ULL : (1ULL << bw) - 1;
+  v &= mask;
+  return bw < 64 && (v >> (bw - 1)) ? (int64_t)v - (int64_t)(1ULL << bw) : (int64_t)v;
+}
+
+int main(int argc, char **argv) {
+  const int logn = argc > 1 ? std::atoi(argv[1]) : 16;
+  const bool full = argc > 2 && std::atoi(argv[2]);
+  const int n = 1 << logn, bw = 32, k = 12;
+  const u64 mask = (1ULL << bw) - 1;
+  std::mt19937_64 rng(0x4D264D);
+
+  Party A{1}, B{2};
+  auto ios = mm::LoopbackIO::MakePair();
+  A.io = std::move(ios.first);
+  B.io = std::move(ios.second);
+  auto box = std::make_shared<mm::IdealCOT::Mailbox>();
+  A.cot.reset(new mm::IdealCOT(box, 1));
+  B.cot.reset(new mm::IdealCOT(box, 2));
+  both(A, B, [&](Party &p) {  // key generation + pk exchange happen in the constructor
+    p.linear.reset(new CheetahLinear(p.id, p.io.get(), 1ULL << bw));
+    p.trunc.reset(new mm::Truncation(p.id, p.cot.get()));
+  });
+  const u64 prime = A.linear->field_mod();
+  EXPECT(prime == 4293918721ULL, "field prime for l=32 (constants.h:46)");
+
+  // ---- BOLE with truncation: tests/bole_test.cpp:170-300 --------------------------------------
+  {
+    std::vector<int64_t> x(n), y(n);
+    std::vector<u64> xs[2], ys[2], xf[2], yf[2], zf[2], zr[2];
+    for (auto *v : {&xs[0], &xs[1], &ys[0], &ys[1], &xf[0], &xf[1], &yf[0], &yf[1], &zf[0], &zf[1], &zr[0], &zr[1]}) v->resize(n);
+    for (int i = 0; i < n; ++i) {
+      x[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      y[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
+      ys[0][i] = rng() & mask, ys[1][i] = ((u64)y[i] - ys[0][i]) & mask;
+    }
+    CheetahLinear::BNMeta meta{TensorShape({0, 0, 0}), TensorShape({n}), prime, true};
+    both(A, B, [&](Party &p) {
+      const int s = p.id - 1;
+      p.trunc->ring_to_field(n, xs[s].data(), xf[s].data(), bw, prime);
+      p.trunc->ring_to_field(n, ys[s].data(), yf[s].data(), bw, prime);
+      Tensor<u64> tx = Tensor<u64>::Wrap(xf[s].data(), meta.vec_shape), ty = Tensor<u64>::Wrap(yf[s].data(), meta.vec_shape);
+      Tensor<u64> out = Tensor<u64>::Wrap(zf[s].data(), meta.vec_shape);
+      p.linear->BOLE(tx, ty, meta, out);
+      p.trunc->field_to_ring_with_truncate(n, zf[s].data(), zr[s].data(), prime, bw, k);
+    });
+    bool exact_field = true, trunc_ok = true;
+    for (int i = 0; i < n; ++i) {
+      const int64_t prod = x[i] * y[i];
+      const u64 f = (zf[0][i] + zf[1][i]) % prime, want = (u64)((prod % (int64_t)prime + (int64_t)prime) % (int64_t)prime);
+      exact_field &= f == want;                                                     // bole_test.cpp:164-167
+      const int64_t got = to_signed(zr[0][i] + zr[1][i], bw);
+      trunc_ok &= std::llabs(got - (prod >> k)) <= 1;                               // bole_test.cpp:286-289
+    }
+    EXPECT(exact_field, "BOLE: x*y reconstructs exactly in the field");
+    EXPECT(trunc_ok, "BOLE + field_to_ring_with_truncate: |err| <= 1");
+  }
+
+  // ---- BatchNorm flow (flags 0 0): ring_to_field -> bn -> field_to_ring, bole_test.cpp:317+ -------
+  {
+    std::vector<int64_t> x(n), sc(n);
+    std::vector<u64> xs[2], xf[2], zf[2], zr[2], scale(n);
+    for (auto *v : {&xs[0], &xs[1], &xf[0], &xf[1], &zf[0], &zf[1], &zr[0], &zr[1]}) v->resize(n);
+    for (int i = 0; i < n; ++i) {
+      x[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      sc[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      scale[i] = (u64)((sc[i] + (int64_t)prime) % (int64_t)prime);
+      xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
+    }
+    CheetahLinear::BNMeta meta{TensorShape({0, 0, 0}), TensorShape({n}), prime, true};
+    both(A, B, [&](Party &p) {
+      const int s = p.id - 1;
+      p.trunc->ring_to_field(n, xs[s].data(), xf[s].data(), bw, prime);
+      Tensor<u64> tx = Tensor<u64>::Wrap(xf[s].data(), meta.vec_shape), tsc = Tensor<u64>::Wrap(scale.data(), meta.vec_shape);
+      Tensor<u64> out = Tensor<u64>::Wrap(zf[s].data(), meta.vec_shape);
+      p.linear->bn(tx, tsc, meta, out);
+      for (int i = 0; i < n; ++i) zf[s][i] %= prime;
+      p.trunc->field_to_ring(n, zf[s].data(), zr[s].data(), prime, bw);
+    });
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok &= to_signed(zr[0][i] + zr[1][i], bw) == x[i] * sc[i];
+    EXPECT(ok, "BatchNorm: ring_to_field -> bn -> field_to_ring exact");
+  }
+
+  // ---- conversions alone: tests/ring_to_field_test.cpp, field_to_ring_test.cpp, ring_extension_test.cpp ----
+  {
+    std::vector<int64_t> v(n);
+    std::vector<u64> s[2], f[2], r[2];
+    std::vector<unsigned __int128> w[2];
+    for (int q = 0; q < 2; ++q) s[q].resize(n), f[q].resize(n), r[q].resize(n), w[q].resize(n);
+    for (int i = 0; i < n; ++i) {
+      v[i] = (int64_t)(rng() % (1ULL << (bw - 2))) - (1LL << (bw - 3));
+      s[0][i] = rng() & mask, s[1][i] = ((u64)v[i] - s[0][i]) & mask;
+    }
+    both(A, B, [&](Party &p) {
+      const int q = p.id - 1;
+      p.trunc->ring_to_field(n, s[q].data(), f[q].data(), bw, prime);
+      for (int i = 0; i < n; ++i) f[q][i] %= prime;
+      p.trunc->field_to_ring(n, f[q].data(), r[q].data(), prime, bw);
+      p.trunc->ring_to_ring128(n, s[q].data(), w[q].data(), bw, bw + 64);
+    });
+    bool r2f = true, f2r = true, ext = true;
+    const unsigned __int128 m96 = (((unsigned __int128)1) << 96) - 1;
+    for (int i = 0; i < n; ++i) {
+      r2f &= (f[0][i] + f[1][i]) % prime == (u64)((v[i] % (int64_t)prime + (int64_t)prime) % (int64_t)prime);
+      f2r &= to_signed(r[0][i] + r[1][i], bw) == v[i];
+      ext &= ((w[0][i] + w[1][i]) & m96) == (((unsigned __int128)(__int128)v[i]) & m96);
+    }
+    EXPECT(r2f, "ring_to_field exact (ring_to_field_test.cpp:128-143)");
+    EXPECT(f2r, "field_to_ring exact (field_to_ring_test.cpp:121-135)");
+    EXPECT(ext, "ring_to_ring128 32 -> 96 bits exact (ring_extension_test.cpp:100-119)");
+  }
+
+  // ---- HomConv and HomFC over a 2^37 ring (shipped ell=37, scripts/common.sh:48-56) ----------------
+  {
+    const int l = 37;
+    const u64 m37 = (1ULL << l) - 1;
+    Party A2{1}, B2{2};
+    auto io2 = mm::LoopbackIO::MakePair();
+    A2.io = std::move(io2.first);
+    B2.io = std::move(io2.second);
+    both(A2, B2, [&](Party &p) { p.linear.reset(new CheetahLinear(p.id, p.io.get(), 1ULL << l)); });
+    const int C = full ? 64 : 6, H = full ? 56 : 14, M = full ? 64 : 4;
+    CheetahLinear::ConvMeta meta{TensorShape({C, H, H}), TensorShape({C, 3, 3}), (size_t)M, Padding::SAME, 1, true};
+    Tensor<u64> img(meta.ishape), sh[2] = {Tensor<u64>(meta.ishape), Tensor<u64>(meta.ishape)};
+    std::vector<int64_t> xv(C * H * H);
+    for (int i = 0; i < C * H * H; ++i) {
+      xv[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      sh[0].data()[i] = rng() & m37, sh[1].data()[i] = ((u64)xv[i] - sh[0].data()[i]) & m37;
+    }
+    std::vector<Tensor<u64>> filters(M, Tensor<u64>(meta.fshape));
+    std::vector<int64_t> wv(M * C * 9);
+    for (int mm_ = 0; mm_ < M; ++mm_)
+      for (int i = 0; i < C * 9; ++i) {
+        wv[mm_ * C * 9 + i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+        filters[mm_].data()[i] = (u64)wv[mm_ * C * 9 + i] & m37;
+      }
+    Tensor<u64> out[2];
+    both(A2, B2, [&](Party &p) { p.linear->conv2d(sh[p.id - 1], filters, meta, out[p.id - 1]); });
+    bool ok = out[0].shape().IsSameSize(TensorShape({M, H, H}));
+    for (int m_ = 0; m_ < M && ok; ++m_)
+      for (int oh = 0; oh < H; ++oh)
+        for (int ow = 0; ow < H; ++ow) {
+          int64_t acc = 0;  // Tensor::Conv2D, tensor.h:320-362, SAME padding (pad 1)
+          for (int c = 0; c < C; ++c)
+            for (int r = 0; r < 3; ++r)
+              for (int s = 0; s < 3; ++s) {
+                const int ih = oh + r - 1, iw = ow + s - 1;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= H) continue;
+                acc += wv[(m_ * C + c) * 9 + r * 3 + s] * xv[(c * H + ih) * H + iw];
+              }
+          const int64_t got = to_signed(out[0](m_, oh, ow) + out[1](m_, oh, ow), l);
+          ok &= std::llabs(got - acc) <= 1;      // library_fixed_uniform_cheetah.cpp:199
+        }
+    EXPECT(ok, full ? "conv2d ResNet50 3x3 56x56x64->64: |err| <= 1" : "conv2d 6x14x14 3x3 SAME: |err| <= 1");
+
+    const int rows = full ? 1001 : 37, cols = full ? 2048 : 300;
+    CheetahLinear::FCMeta fm{TensorShape({cols}), TensorShape({rows, cols}), true};
+    Tensor<u64> W(fm.weight_shape), vs[2] = {Tensor<u64>(fm.input_shape), Tensor<u64>(fm.input_shape)}, fo[2];
+    std::vector<int64_t> vv(cols), ww((size_t)rows * cols);
+    for (int i = 0; i < cols; ++i) {
+      vv[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      vs[0].data()[i] = rng() & m37, vs[1].data()[i] = ((u64)vv[i] - vs[0].data()[i]) & m37;
+    }
+    for (size_t i = 0; i < ww.size(); ++i) {
+      ww[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      W.data()[i] = (u64)ww[i] & m37;
+    }
+    both(A2, B2, [&](Party &p) { p.linear->fc(vs[p.id - 1], W, fm, fo[p.id - 1]); });
+    bool fok = true;
+    for (int r = 0; r < rows; ++r) {
+      int64_t acc = 0;
+      for (int c = 0; c < cols; ++c) acc += ww[(size_t)r * cols + c] * vv[c];
+      fok &= std::llabs(to_signed(fo[0](r) + fo[1](r), l) - acc) <= 1;  // library_fixed_uniform_cheetah.cpp:404
+    }
+    EXPECT(fok, "fc: |err| <= 1");
+    std::printf("INFO bytes sent: alice %llu bob %llu\n", (unsigned long long)A2.linear->io_counter(),
+                (unsigned long long)B2.linear->io_counter());
+    // error behaviour: shape mismatch throws invalid_argument like cheetah-api.cpp:381-383
+    bool threw = false;
+    try {
+      Tensor<u64> bad(TensorShape({C, H, H + 1}));
+      A2.linear->conv2d(bad, filters, meta, out[0]);
+    } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw, "conv2d shape mismatch throws std::invalid_argument");
+  }
+  std::printf("%s (%d failures)\n", g_fail ? "FAILED" : "ALL PASSED", g_fail);
+  return g_fail ? 1 : 0;
+}
