@@ -114,3 +114,32 @@ def test_conv_errors(mm):
     with pytest.raises(mm.MMHError) as ei:   # no public key -> ERR_CONFIG
         h.conv2DSS(None, None, None, meta, None)
     assert ei.value.code == 1
+
+
+def test_sharded_conv_single_rank_equals_unsharded(mm):
+    """world_size 1 on the GPU: ShardedConv must be the identity wrapper around conv2DSS"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    from openmm_amd.sharding import ShardedConv
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = mm.Context(N, (60, 49), T)
+        smp = mm.Sampler(g, key=bytes(range(32)))
+        sk, pk = smp.keygen()
+        meta = Meta((4, 10, 10), (4, 3, 3), 5, 1, 1, True)
+        srv = HomConv2DSS()
+        srv.setUp(g, pk_ntt=pk)
+        plan = srv.plan(meta)
+        cts, share1 = smp.uniform(plan.n_in), torch.randint(0, T, (4, 10, 10), dtype=torch.int64, device="cuda")
+        filters = torch.randint(1, 1 << 12, (5, 4, 3, 3), dtype=torch.int64, device="cuda")
+        rand = (smp.ternary(plan.n_out), smp.noise(plan.n_out), smp.uniform(plan.n_out, lv=1)[:, 0].contiguous())
+        s1 = srv.encodeImage(share1, meta)
+        ref = srv.conv2DSS(cts, s1, srv.encodeFilters(filters, meta), meta, rand)
+        got = ShardedConv(srv, meta).run(cts, s1, filters, lambda n: tuple(r[:n] for r in rand))
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,91 @@
+"""CPU, gloo, world_size 2 and 3: the sharding layer partitions units and reassembles them
+exactly as the unsharded call, ragged and empty shards included."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class FakeServer:
+    """Stands in for HomConv2DSS on CPU: deterministic functions of the filter slice, so that
+    any mix-up of ranges or ordering changes the result."""
+
+    class P:
+        n_spatial = 3
+        out_shape = (0, 4, 5)
+
+    def plan(self, meta):
+        return self.P
+
+    def encodeFilters(self, filters, meta):
+        assert filters.shape[0] == meta.n_filters
+        return filters
+
+    def conv2DSS(self, s0, s1, f, meta, rand):
+        m = f.shape[0]
+        key = f.reshape(m, -1).sum(1)
+        cts = (key[:, None, None] * 7 + torch.arange(self.P.n_spatial)[None, :, None] + rand[0]).expand(m, 3, 8)
+        cts = cts.reshape(m * 3, 2, 1, 4).contiguous()
+        share = (key[:, None, None] + torch.arange(20).reshape(1, 4, 5)).contiguous()
+        return cts, share
+
+
+def _worker(rank, world, port, n_filters, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openmm_amd.hom_conv2d_ss import Meta
+    from openmm_amd.sharding import ShardedConv, shard_range, sharded_elementwise
+    try:
+        filters = torch.arange(n_filters * 2 * 3 * 3, dtype=torch.int64).reshape(n_filters, 2, 3, 3)
+        meta = Meta((2, 8, 8), (2, 3, 3), n_filters, 1, 1, True)
+        srv = FakeServer()
+        sc = ShardedConv(srv, meta)
+        lo, hi = shard_range(n_filters, world, rank)
+        assert (sc.lo, sc.hi) == (lo, hi)
+        s0 = torch.zeros((2, 2, 2, 4), dtype=torch.int64)
+        cts, share = sc.run(s0, s0, filters, lambda n: (5,))
+        x = torch.arange(1000, dtype=torch.int64)
+        y = sharded_elementwise(lambda t: t * 3 + 1, x)
+        if rank == 0:
+            ref_cts, ref_share = srv.conv2DSS(s0, s0, filters, meta, (5,))
+            q.put((torch.equal(cts, ref_cts), torch.equal(share, ref_share), torch.equal(y, x * 3 + 1)))
+        else:
+            assert cts is None and share is None and y is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_filters", [(2, 6), (2, 5), (3, 2), (3, 7)])
+def test_sharded_conv_gloo(world, n_filters):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_filters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == (True, True, True)
+
+
+def test_shard_range_matches_launchworks():
+    from openmm_amd.sharding import shard_range
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, w, r) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            per = (n + w - 1) // w
+            assert all(hi - lo <= per for lo, hi in parts)
