@@ -26,6 +26,11 @@ struct DevMod {
   const ulonglong2 *fwd;       // length N
   const ulonglong2 *inv;       // length N, inverses of fwd
   u64 tw_offset;               // fwd = tables + tw_offset, inv = fwd + N (one allocation per context)
+  // q = 2^b - c with c < 2^31 (every prime SEAL's generator emits): v mod q ~ (v mod 2^b) + (v >> b)*c
+  u32 fold_c;                  // c, or 0 when q does not have that shape
+  u32 fold_shift;              // b - 32
+  u32 fold_mask;               // 2^(b-32) - 1
+  u32 pad_;
 };
 
 // A modulus without NTT tables (plain modulus t, BEHZ gamma): Barrett only.
@@ -113,19 +118,49 @@ __device__ __forceinline__ u32 dot4_lo(u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u
       : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
   return (u32)d;
 }
+__device__ __forceinline__ u64 make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
-// x*w mod q in [0, 3q) for any 64-bit x: Shoup whose high product drops only the low partial
-// product x0*s0 (quotient short by at most 1).  nq = 2^64 - q.  9 mads.
-__device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wsh, u64 nq) {
-  const u32 x0 = lo32(x), x1 = hi32(x), s0 = lo32(wsh), s1 = hi32(wsh);
-  const u64 m1 = (u64)x1 * s0;
-  const u64 m2 = (u64)x0 * s1 + m1;
-  const u64 c = (m2 >> 32) | ((u64)(m2 < m1) << 32);
-  const u64 h = (u64)x1 * s1 + c;
-  const u32 h0 = lo32(h), h1 = hi32(h);
-  const u64 t = (u64)h0 * lo32(nq) + (u64)x0 * lo32(w);
+// High word of the Shoup quotient, floor(x*wsh / 2^64) short by at most 1 (the low partial product
+// x0*s0 is dropped; the carry of the two middle products is kept).  Returned as halves so that
+// the carry can ride on the high half: 5 VALU instructions.
+__device__ __forceinline__ void shoup_quotient(u32 x0, u32 x1, u32 s0, u32 s1, u32 &h0, u32 &h1) {
+  u64 m, h, cy, cy2;
+  u32 hc, vcc_out;
+  asm("v_mad_u64_u32 %0, %2, %5, %6, 0\n\t"        // m  = x1*s0
+      "v_mad_u64_u32 %0, %2, %4, %7, %0\n\t"       // m += x0*s1, carry -> cy
+      "v_lshrrev_b64 %0, 32, %0\n\t"               // m >>= 32
+      "v_mad_u64_u32 %1, %3, %5, %7, %0"             // h  = x1*s1 + m
+      : "=&v"(m), "=&v"(h), "=&s"(cy), "=&s"(cy2)
+      : "v"(x0), "v"(x1), "v"(s0), "v"(s1));
+  h0 = lo32(h);
+  asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(hc), "=s"(cy2) : "v"(hi32(h)), "s"(cy));
+  (void)vcc_out;
+  h1 = hc;
+}
+
+// base + x*w mod q with the product lazily in [0, 3q): Shoup multiplication whose accumulator
+// starts at `base`, so that the butterfly's addition costs nothing.  nq = 2^64 - q.  12 VALU.
+__device__ __forceinline__ u64 shoup_mad(u64 base, u64 x, u64 w, u64 wsh, u64 nq) {
+  const u32 x0 = lo32(x), x1 = hi32(x);
+  u32 h0, h1;
+  shoup_quotient(x0, x1, lo32(wsh), hi32(wsh), h0, h1);
+  u64 t, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %6\n\t"
+      "v_mad_u64_u32 %0, %1, %4, %5, %0"
+      : "=&v"(t), "=&s"(cy)
+      : "v"(x0), "v"(lo32(w)), "v"(h0), "s"(lo32(nq)), "v"(base));
   const u32 acc = dot4_lo(x0, hi32(w), x1, lo32(w), h0, hi32(nq), h1, lo32(nq));
-  return t + ((u64)acc << 32);
+  u32 hi;  // opaque add: hipcc otherwise widens this to a 64-bit add of {0, acc} (three instructions)
+  asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"(hi32(t)), "v"(acc));
+  return make64(lo32(t), hi);
+}
+__device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wsh, u64 nq) { return shoup_mad(0, x, w, wsh, nq); }
+
+// Partial reduction for q = 2^b - c: any 64-bit v becomes (v mod 2^b) + (v >> b)*c = v (mod q),
+// below 2q whenever c*2^(64-b) < q - 2^b + q (checked when the context is built).  3 VALU.
+__device__ __forceinline__ u64 fold_mod(u64 v, u32 c, u32 shift, u32 mask) {
+  const u32 hi = hi32(v);
+  return (u64)(hi >> shift) * c + make64(lo32(v), hi & mask);
 }
 __device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 wsh, u64 q) {
   return csub(mul_shoup_lazy(x, w, wsh, q), q);

@@ -35,6 +35,19 @@ static void build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out, std::vector<ulo
   out->ninv = inv_mod((u64)N % m, m);
   out->ninv_sh = shoup(out->ninv, m);
   out->tw_offset = base;
+  // pseudo-Mersenne shape used by the NTT's partial reductions
+  const int b = bit_count(m);
+  const u64 c = b >= 64 ? 0 : (u64(1) << b) - m;
+  out->fold_c = out->fold_shift = out->fold_mask = out->pad_ = 0;
+  if (b >= 32 && b <= 60 && c < (u64(1) << 31)) {
+    // a folded value is at most 2^b - 1 + (2^(64-b) - 1)*c and must stay below 2q
+    const u128 worst = ((u128)1 << b) - 1 + (u128)((u64(1) << (64 - b)) - 1) * c;
+    if (worst < 2 * (u128)m) {
+      out->fold_c = (u32)c;
+      out->fold_shift = (u32)(b - 32);
+      out->fold_mask = (u32)((u64(1) << (b - 32)) - 1);
+    }
+  }
 }
 static ModC make_modc(u64 m) {
   const u128 ratio = m & (m - 1) ? ~(u128)0 / m : (~(u128)0 / m) + 1;
@@ -127,7 +140,8 @@ extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t
   MMH_REQUIRE(L >= 1 && L <= (size_t)kMaxLimbs, MMH_ERR_CONFIG);
   MMH_REQUIRE(t == 0 || L <= 2, MMH_ERR_CONFIG);
   for (size_t l = 0; l < L; ++l) {
-    MMH_REQUIRE(bit_count(q[l]) <= 61 && is_prime(q[l]) && q[l] % (2 * N) == 1, MMH_ERR_INVALID_ARG);
+    // SEAL_USER_MOD_BIT_COUNT_MAX = 60; the NTT's lazy ranges use the headroom up to 16q < 2^64
+    MMH_REQUIRE(bit_count(q[l]) <= 60 && is_prime(q[l]) && q[l] % (2 * N) == 1, MMH_ERR_INVALID_ARG);
     MMH_REQUIRE(t == 0 || q[l] > t, MMH_ERR_INVALID_ARG);  // fast plain lift needs q_l > t
     for (size_t k = 0; k < l; ++k) MMH_REQUIRE(q[k] != q[l], MMH_ERR_INVALID_ARG);
   }

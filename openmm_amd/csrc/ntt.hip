@@ -5,7 +5,7 @@
 //   pass B  radix-16 on 16-element groups of stride 16 exchanged through LDS,
 //   pass C  radix-16 on 16 consecutive elements, then a coalesced 16-B/lane store.
 // 64-bit Harvey butterflies with Shoup twiddles (w, floor(w 2^64/q)) on VALU; values stay
-// lazily reduced in [0,8q) and are corrected once at the end,
+// lazily reduced (below 16q forward, 4q inverse) and are corrected once at the end,
 // so the visible result equals seal::util::ntt_negacyclic_harvey /
 // inverse_ntt_negacyclic_harvey (hom_conv2d_ss.cc:306,315,333): bit-reversed order,
 // fully reduced.
@@ -18,12 +18,48 @@ namespace mmh {
 
 __device__ __forceinline__ int pad(int j) { return j + (j >> 4); }
 
+// x >= m ? x - m : x
+__device__ __forceinline__ u64 csub64(u64 x, u64 m) { return x >= m ? x - m : x; }
+
+// How a kernel keeps its lazy values bounded.  FOLD (q = 2^b - c, all SEAL-generated primes):
+// a 3-instruction partial reduction to < 2q every third stage.  Otherwise conditional
+// subtractions (5 instructions) every other stage.
+template <bool FOLD>
+struct Reducer {
+  u64 q, q2, q4, q8;
+  u32 c, shift, mask;
+  __device__ __forceinline__ explicit Reducer(const DevMod &M)
+      : q(M.q), q2(2 * M.q), q4(4 * M.q), q8(8 * M.q), c(M.fold_c), shift(M.fold_shift), mask(M.fold_mask) {}
+  // forward stage s: X must be small enough that X + 4q stays below 2^64 after the stage
+  __device__ __forceinline__ u64 fwd_x(u64 X, int s) const {
+    if (FOLD) return (s % 3 == 0 && s > 0) ? fold_mod(X, c, shift, mask) : X;  // < 4q,8q,12q -> 16q -> fold
+    return (s & 1) ? csub64(X, q8) : X;                                        // < 12q / < 16q alternating
+  }
+  // to [0, q) from the bound the last forward stage leaves
+  __device__ __forceinline__ u64 fwd_final(u64 v) const {
+    if (FOLD) return csub64(fold_mod(v, c, shift, mask), q);
+    return csub64(csub64(csub64(csub64(v, q8), q4), q2), q);
+  }
+  // inverse stage e (e-th executed).  X - Y + bias must stay below 2^64 without wrapping, so inputs
+  // stay under 8q: FOLD alternates inputs < 3q (products of the previous stage; sums < 6q are left
+  // alone) and inputs < 6q (sums < 12q are folded under 2q).  Otherwise inputs < 4q at every stage.
+  __device__ __forceinline__ u64 inv_sum(u64 S, int e) const {
+    if (FOLD) return (e & 1) ? fold_mod(S, c, shift, mask) : S;
+    return csub64(S, q4);
+  }
+  __device__ __forceinline__ u64 inv_bias(int e) const {  // multiple of q that is >= any input Y
+    if (FOLD) return (e & 1) ? q8 : q4;
+    return q4;
+  }
+};
+
 // R radix-2 stages (forward, Cooley-Tukey) on 2^R register-resident elements.
 // Element k of the group sits at index jhi*(G<<R) + k*G + jlo; stage u pairs k with
 // k + 2^(R-1-u) and uses twiddle fwd[2^(S0+u) + (jhi<<u) + (k >> (R-u))].
-template <int R, int S0>
+// A butterfly maps X < B to outputs X + T and X + 4q - T, both < B + 4q (T < 3q); Y is unconstrained.
+template <int R, int S0, bool FOLD>
 __device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__restrict__ tw,
-                                          u32 jhi, u64 nq, u64 q4) {
+                                          u32 jhi, u64 nq, const Reducer<FOLD> &rd) {
 #pragma unroll
   for (int u = 0; u < R; ++u) {
     const int half = 1 << (R - 1 - u);
@@ -34,24 +70,25 @@ __device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__
 #pragma unroll
       for (int i = 0; i < half; ++i) {
         const int k0 = b * 2 * half + i, k1 = k0 + half;
-        u64 X = x[k0];
-        X -= (X >= q4) ? q4 : 0;
-        const u64 T = mul_shoup_lazy4(x[k1], w.x, w.y, nq);
-        x[k0] = X + T;
-        x[k1] = X + q4 - T;
+        const u64 X = rd.fwd_x(x[k0], S0 + u);
+        const u64 A = shoup_mad(X, x[k1], w.x, w.y, nq);  // X + T
+        x[k0] = A;
+        x[k1] = 2 * X + rd.q4 - A;                        // X + 4q - T
       }
     }
   }
 }
 
-// The same stages run backwards (Gentleman-Sande) with the inverse twiddles.
-template <int R, int S0>
+// The same stages run backwards (Gentleman-Sande) with the inverse twiddles; E0 = number of
+// stages already executed.  Sums double the bound, differences go through the multiplier (< 3q).
+template <int R, int S0, int E0, bool FOLD>
 __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 *__restrict__ tw,
-                                          u32 jhi, u64 nq, u64 q4) {
+                                          u32 jhi, u64 nq, const Reducer<FOLD> &rd) {
 #pragma unroll
   for (int u = R - 1; u >= 0; --u) {
     const int half = 1 << (R - 1 - u);
     const u32 base = (1u << (S0 + u)) + (jhi << u);
+    const int e = E0 + (R - 1 - u);
 #pragma unroll
     for (int b = 0; b < (1 << u); ++b) {
       const ulonglong2 w = tw[base + b];
@@ -59,16 +96,14 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 *__
       for (int i = 0; i < half; ++i) {
         const int k0 = b * 2 * half + i, k1 = k0 + half;
         const u64 X = x[k0], Y = x[k1];
-        u64 s = X + Y;
-        s -= (s >= q4) ? q4 : 0;
-        x[k0] = s;
-        x[k1] = mul_shoup_lazy4(X + q4 - Y, w.x, w.y, nq);
+        x[k0] = rd.inv_sum(X + Y, e);
+        x[k1] = mul_shoup_lazy4(X + rd.inv_bias(e) - Y, w.x, w.y, nq);
       }
     }
   }
 }
 
-template <int LOGN>
+template <int LOGN, bool FOLD>
 __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
@@ -77,7 +112,8 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
   const DevMod &M = mods[mod_base + blockIdx.x % limbs];
-  const u64 q = M.q, q2 = 2 * q, q4 = 4 * q, nq = M.nq;
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
@@ -85,7 +121,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[EA];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
-    fwd_radix<RA, 0>(x, tw, 0, nq, q4);
+    fwd_radix<RA, 0, FOLD>(x, tw, 0, nq, rd);
 #pragma unroll
     for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = x[k];
   }
@@ -96,7 +132,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
-    fwd_radix<4, RA>(x, tw, jhi, nq, q4);
+    fwd_radix<4, RA, FOLD>(x, tw, jhi, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
   }
@@ -107,14 +143,10 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
-    fwd_radix<4, RA + 4>(x, tw, g, nq, q4);
+    fwd_radix<4, RA + 4, FOLD>(x, tw, g, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      u64 v = x[k];
-      v -= (v >= q4) ? q4 : 0;
-      v -= (v >= q2) ? q2 : 0;
-      v -= (v >= q) ? q : 0;
-      lds[17 * g + k] = v;
+      lds[17 * g + k] = rd.fwd_final(x[k]);
     }
   }
   __syncthreads();
@@ -126,7 +158,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   }
 }
 
-template <int LOGN>
+template <int LOGN, bool FOLD>
 __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
@@ -135,7 +167,8 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
   const DevMod &M = mods[mod_base + blockIdx.x % limbs];
-  const u64 q = M.q, q2 = 2 * q, q4 = 4 * q, nq = M.nq;
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset + N;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
@@ -154,7 +187,7 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
-    inv_radix<4, RA + 4>(x, tw, g, nq, q4);
+    inv_radix<4, RA + 4, 0, FOLD>(x, tw, g, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[17 * g + k] = x[k];
   }
@@ -165,7 +198,7 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
-    inv_radix<4, RA>(x, tw, jhi, nq, q4);
+    inv_radix<4, RA, 4, FOLD>(x, tw, jhi, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
   }
@@ -174,14 +207,11 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[EA];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
-    inv_radix<RA, 0>(x, tw, 0, nq, q4);
+    inv_radix<RA, 0, 8, FOLD>(x, tw, 0, nq, rd);
     const u64 ninv = M.ninv, ninv_sh = M.ninv_sh;
 #pragma unroll
     for (int k = 0; k < EA; ++k) {
-      u64 v = mul_shoup_lazy4(x[k], ninv, ninv_sh, nq);
-      v -= (v >= q2) ? q2 : 0;
-      v -= (v >= q) ? q : 0;
-      a[k * 256 + t] = v;
+      a[k * 256 + t] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
     }
   }
 }
@@ -192,9 +222,10 @@ static constexpr size_t lds_bytes() {
 }
 
 template <int LOGN>
-static int launch(bool inverse, u64 *d, const DevMod *mods, const ulonglong2 *tables, size_t blocks,
+static int launch(bool inverse, bool fold, u64 *d, const DevMod *mods, const ulonglong2 *tables, size_t blocks,
                   int limbs, int mod_base, hipStream_t s) {
-  auto kern = inverse ? ntt_inv_kernel<LOGN> : ntt_fwd_kernel<LOGN>;
+  auto kern = inverse ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
+                      : (fold ? ntt_fwd_kernel<LOGN, true> : ntt_fwd_kernel<LOGN, false>);
   if (lds_bytes<LOGN>() > 48 * 1024)  // per device and cheap: set on every launch
     MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<LOGN>()));
@@ -209,9 +240,11 @@ int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys,
   const size_t blocks = n_polys * (size_t)limbs;
   if (blocks == 0) return MMH_OK;
   MMH_REQUIRE(blocks <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
+  bool fold = true;  // every modulus of this launch must have the 2^b - c shape for the fast reducer
+  for (int l = 0; l < limbs; ++l) fold = fold && ctx->h_mods[mod_base + l].fold_c != 0;
   switch (ctx->logN) {
-    case 12: return launch<12>(inverse, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
-    case 13: return launch<13>(inverse, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
+    case 12: return launch<12>(inverse, fold, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
+    case 13: return launch<13>(inverse, fold, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
     default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
   }
 }

@@ -96,3 +96,34 @@ def test_full_size_roundtrip_and_linearity(mm):
     o = OracleCtx(4096, (60, 49), 0)
     for k in (0, n - 1):
         assert np.array_equal(to_host(fs[k]), o.ntt_forward(to_host(s[k])))
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_generic_primes_take_the_conditional_subtract_path(mm, N):
+    """primes that are not 2^b - c use the kernel variant without the fold reduction"""
+    from openmm_amd.lib import to_device, to_host
+    q = [844424930181121, 864691128455200769, 576461851815641089]
+    o, g = OracleCtx(N, q=q), mm.Context(N, q=q)
+    assert g.psi == o.psi
+    a = _polys(o, 5, SEED + 3)
+    a[0, :, :4] = np.array(q, dtype=np.uint64)[:, None] - 1
+    d = to_device(a)
+    g.ntt_forward(d)
+    assert np.array_equal(to_host(d), o.ntt_forward(a))
+    g.ntt_inverse(d)
+    assert np.array_equal(to_host(d), a)
+
+
+def test_worst_case_magnitudes(mm):
+    """all coefficients q-1 with lazy offsets: the largest values the lazy ranges must carry"""
+    from openmm_amd.lib import to_device, to_host
+    o, g = OracleCtx(4096, (60, 49), 0), mm.Context(4096, (60, 49), 0)
+    qs = np.array(o.q, dtype=np.uint64)[None, :, None]
+    a = np.broadcast_to(qs - 1, (2, 2, 4096)).copy()
+    ref = o.ntt_forward(a)
+    d = to_device(a + 3 * qs)          # forward accepts < 4q
+    g.ntt_forward(d)
+    assert np.array_equal(to_host(d), ref)
+    d = to_device(ref + qs)            # inverse accepts < 2q
+    g.ntt_inverse(d)
+    assert np.array_equal(to_host(d), a)
