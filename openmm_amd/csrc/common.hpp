@@ -120,47 +120,50 @@ __device__ __forceinline__ u32 dot4_lo(u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u
 }
 __device__ __forceinline__ u64 make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
-// High word of the Shoup quotient, floor(x*wsh / 2^64) short by at most 1 (the low partial product
-// x0*s0 is dropped; the carry of the two middle products is kept).  Returned as halves so that
-// the carry can ride on the high half: 5 VALU instructions.
-__device__ __forceinline__ void shoup_quotient(u32 x0, u32 x1, u32 s0, u32 s1, u32 &h0, u32 &h1) {
-  u64 m, h, cy, cy2;
-  u32 hc, vcc_out;
-  asm("v_mad_u64_u32 %0, %2, %5, %6, 0\n\t"        // m  = x1*s0
-      "v_mad_u64_u32 %0, %2, %4, %7, %0\n\t"       // m += x0*s1, carry -> cy
-      "v_lshrrev_b64 %0, 32, %0\n\t"               // m >>= 32
-      "v_mad_u64_u32 %1, %3, %5, %7, %0"             // h  = x1*s1 + m
-      : "=&v"(m), "=&v"(h), "=&s"(cy), "=&s"(cy2)
-      : "v"(x0), "v"(x1), "v"(s0), "v"(s1));
-  h0 = lo32(h);
-  asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(hc), "=s"(cy2) : "v"(hi32(h)), "s"(cy));
-  (void)vcc_out;
-  h1 = hc;
-}
-
 // base + x*w mod q with the product lazily in [0, 3q): Shoup multiplication whose accumulator
-// starts at `base`, so that the butterfly's addition costs nothing.  nq = 2^64 - q.  12 VALU.
-__device__ __forceinline__ u64 shoup_mad(u64 base, u64 x, u64 w, u64 wsh, u64 nq) {
-  const u32 x0 = lo32(x), x1 = hi32(x);
-  u32 h0, h1;
-  shoup_quotient(x0, x1, lo32(wsh), hi32(wsh), h0, h1);
-  u64 t, cy;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %6\n\t"
-      "v_mad_u64_u32 %0, %1, %4, %5, %0"
-      : "=&v"(t), "=&s"(cy)
-      : "v"(x0), "v"(lo32(w)), "v"(h0), "s"(lo32(nq)), "v"(base));
-  const u32 acc = dot4_lo(x0, hi32(w), x1, lo32(w), h0, hi32(nq), h1, lo32(nq));
-  u32 hi;  // opaque add: hipcc otherwise widens this to a 64-bit add of {0, acc} (three instructions)
-  asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"(hi32(t)), "v"(acc));
+// starts at `base`, so that the butterfly's addition costs nothing.  nq = 2^64 - q.
+// The quotient floor(x*wsh / 2^64) drops only the low partial product x0*s0 (short by at most 1)
+// and keeps the carry of the two middle products on its high half.  12 VALU instructions.
+// TW is "v" for per-lane twiddles and "s" when the twiddle is wave-uniform (pass A), which saves
+// the SGPR->VGPR copies; every instruction reads at most one SGPR.
+#define MMH_SHOUP_MAD_BODY(TW)                                                                        \
+  const u32 x0 = lo32(x), x1 = hi32(x);                                                               \
+  u64 m, h, cy, cy2, t, acc;                                                                          \
+  u32 h1, hi;                                                                                         \
+  asm("v_mad_u64_u32 %0, %2, %5, %6, 0\n\t"  /* m  = x1*s0                  */                        \
+      "v_mad_u64_u32 %0, %2, %4, %7, %0\n\t" /* m += x0*s1, carry -> cy     */                        \
+      "v_lshrrev_b64 %0, 32, %0\n\t"         /* m >>= 32                    */                        \
+      "v_mad_u64_u32 %1, %3, %5, %7, %0"       /* h  = x1*s1 + m              */                        \
+      : "=&v"(m), "=&v"(h), "=&s"(cy), "=&s"(cy2)                                                     \
+      : "v"(x0), "v"(x1), TW(lo32(wsh)), TW(hi32(wsh)));                                              \
+  asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(h1), "=s"(cy2) : "v"(hi32(h)), "s"(cy));           \
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %6\n\t" /* t  = base + x0*w0           */                        \
+      "v_mad_u64_u32 %0, %1, %4, %5, %0"       /* t += h0*nq0                 */                        \
+      : "=&v"(t), "=&s"(cy)                                                                           \
+      : "v"(x0), TW(lo32(w)), "v"(lo32(h)), "s"(lo32(nq)), "v"(base));                                \
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\t"  /* cross terms, low 32 bits    */                        \
+      "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t"                                                          \
+      "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t"                                                          \
+      "v_mad_u64_u32 %0, %1, %8, %9, %0"                                                              \
+      : "=&v"(acc), "=&s"(cy)                                                                         \
+      : "v"(x0), TW(hi32(w)), "v"(x1), TW(lo32(w)), "v"(lo32(h)), "s"(hi32(nq)), "v"(h1), "s"(lo32(nq))); \
+  /* opaque add: hipcc otherwise widens it to a 64-bit add of {0, acc} (three instructions) */        \
+  asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"(hi32(t)), "v"(lo32(acc)));                              \
   return make64(lo32(t), hi);
-}
+
+__device__ __forceinline__ u64 shoup_mad(u64 base, u64 x, u64 w, u64 wsh, u64 nq) { MMH_SHOUP_MAD_BODY("v") }
+__device__ __forceinline__ u64 shoup_mad_uniform(u64 base, u64 x, u64 w, u64 wsh, u64 nq) { MMH_SHOUP_MAD_BODY("s") }
 __device__ __forceinline__ u64 mul_shoup_lazy4(u64 x, u64 w, u64 wsh, u64 nq) { return shoup_mad(0, x, w, wsh, nq); }
 
 // Partial reduction for q = 2^b - c: any 64-bit v becomes (v mod 2^b) + (v >> b)*c = v (mod q),
 // below 2q whenever c*2^(64-b) < q - 2^b + q (checked when the context is built).  3 VALU.
 __device__ __forceinline__ u64 fold_mod(u64 v, u32 c, u32 shift, u32 mask) {
-  const u32 hi = hi32(v);
-  return (u64)(hi >> shift) * c + make64(lo32(v), hi & mask);
+  u32 k, hm;  // opaque steps: hipcc re-associates the C form into five instructions
+  asm("v_lshrrev_b32 %0, %1, %2" : "=v"(k) : "s"(shift), "v"(hi32(v)));
+  asm("v_and_b32 %0, %1, %2" : "=v"(hm) : "s"(mask), "v"(hi32(v)));
+  u64 r, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(k), "s"(c), "v"(make64(lo32(v), hm)));
+  return r;
 }
 __device__ __forceinline__ u64 mul_shoup(u64 x, u64 w, u64 wsh, u64 q) {
   return csub(mul_shoup_lazy(x, w, wsh, q), q);

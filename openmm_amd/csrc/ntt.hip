@@ -53,25 +53,38 @@ struct Reducer {
   }
 };
 
+// The 2^R - 1 twiddles of a radix-2^R group, stage-major: entry (1<<u) - 1 + b is
+// table[2^(S0+u) + (jhi<<u) + b].  Loaded ahead of the barrier that precedes their pass so that the
+// L2 latency overlaps the previous pass (the kernel is LDS-limited to 4 waves per SIMD, which
+// leaves 128 VGPRs per lane).
+template <int R, int S0>
+__device__ __forceinline__ void load_twiddles(const ulonglong2 *__restrict__ tw, u32 jhi,
+                                              ulonglong2 (&w)[(1 << R) - 1]) {
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+#pragma unroll
+    for (int b = 0; b < (1 << u); ++b) w[(1 << u) - 1 + b] = tw[(1u << (S0 + u)) + (jhi << u) + b];
+}
+
 // R radix-2 stages (forward, Cooley-Tukey) on 2^R register-resident elements.
 // Element k of the group sits at index jhi*(G<<R) + k*G + jlo; stage u pairs k with
 // k + 2^(R-1-u) and uses twiddle fwd[2^(S0+u) + (jhi<<u) + (k >> (R-u))].
 // A butterfly maps X < B to outputs X + T and X + 4q - T, both < B + 4q (T < 3q); Y is unconstrained.
-template <int R, int S0, bool FOLD>
-__device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__restrict__ tw,
-                                          u32 jhi, u64 nq, const Reducer<FOLD> &rd) {
+template <int R, int S0, bool FOLD, bool UNIFORM = false>
+__device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 (&tw)[(1 << R) - 1], u64 nq,
+                                          const Reducer<FOLD> &rd) {
 #pragma unroll
   for (int u = 0; u < R; ++u) {
     const int half = 1 << (R - 1 - u);
-    const u32 base = (1u << (S0 + u)) + (jhi << u);
 #pragma unroll
     for (int b = 0; b < (1 << u); ++b) {
-      const ulonglong2 w = tw[base + b];
+      const ulonglong2 w = tw[(1 << u) - 1 + b];
 #pragma unroll
       for (int i = 0; i < half; ++i) {
         const int k0 = b * 2 * half + i, k1 = k0 + half;
         const u64 X = rd.fwd_x(x[k0], S0 + u);
-        const u64 A = shoup_mad(X, x[k1], w.x, w.y, nq);  // X + T
+        const u64 A = UNIFORM ? shoup_mad_uniform(X, x[k1], w.x, w.y, nq)  // X + T
+                              : shoup_mad(X, x[k1], w.x, w.y, nq);
         x[k0] = A;
         x[k1] = 2 * X + rd.q4 - A;                        // X + 4q - T
       }
@@ -81,23 +94,23 @@ __device__ __forceinline__ void fwd_radix(u64 (&x)[1 << R], const ulonglong2 *__
 
 // The same stages run backwards (Gentleman-Sande) with the inverse twiddles; E0 = number of
 // stages already executed.  Sums double the bound, differences go through the multiplier (< 3q).
-template <int R, int S0, int E0, bool FOLD>
-__device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 *__restrict__ tw,
-                                          u32 jhi, u64 nq, const Reducer<FOLD> &rd) {
+template <int R, int S0, int E0, bool FOLD, bool UNIFORM = false>
+__device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 (&tw)[(1 << R) - 1], u64 nq,
+                                          const Reducer<FOLD> &rd) {
 #pragma unroll
   for (int u = R - 1; u >= 0; --u) {
     const int half = 1 << (R - 1 - u);
-    const u32 base = (1u << (S0 + u)) + (jhi << u);
     const int e = E0 + (R - 1 - u);
 #pragma unroll
     for (int b = 0; b < (1 << u); ++b) {
-      const ulonglong2 w = tw[base + b];
+      const ulonglong2 w = tw[(1 << u) - 1 + b];
 #pragma unroll
       for (int i = 0; i < half; ++i) {
         const int k0 = b * 2 * half + i, k1 = k0 + half;
         const u64 X = x[k0], Y = x[k1];
         x[k0] = rd.inv_sum(X + Y, e);
-        x[k1] = mul_shoup_lazy4(X + rd.inv_bias(e) - Y, w.x, w.y, nq);
+        const u64 D = X + rd.inv_bias(e) - Y;
+        x[k1] = UNIFORM ? shoup_mad_uniform(0, D, w.x, w.y, nq) : shoup_mad(0, D, w.x, w.y, nq);
       }
     }
   }
@@ -117,11 +130,15 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
+  ulonglong2 wB[15], wC[15];
   {
     u64 x[EA];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
-    fwd_radix<RA, 0, FOLD>(x, tw, 0, nq, rd);
+    ulonglong2 wA[EA - 1];
+    load_twiddles<RA, 0>(tw, 0, wA);          // wave-uniform: scalar loads
+    load_twiddles<4, RA>(tw, t >> 4, wB);     // for pass B (rep 0), in flight during pass A
+    fwd_radix<RA, 0, FOLD, true>(x, wA, nq, rd);
 #pragma unroll
     for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = x[k];
   }
@@ -132,7 +149,9 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
-    fwd_radix<4, RA, FOLD>(x, tw, jhi, nq, rd);
+    if (rep > 0) load_twiddles<4, RA>(tw, jhi, wB);
+    if (rep == REPS - 1) load_twiddles<4, RA + 4>(tw, t, wC);  // for pass C (rep 0)
+    fwd_radix<4, RA, FOLD>(x, wB, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
   }
@@ -143,11 +162,10 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
-    fwd_radix<4, RA + 4, FOLD>(x, tw, g, nq, rd);
+    if (rep > 0) load_twiddles<4, RA + 4>(tw, g, wC);
+    fwd_radix<4, RA + 4, FOLD>(x, wC, nq, rd);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      lds[17 * g + k] = rd.fwd_final(x[k]);
-    }
+    for (int k = 0; k < 16; ++k) lds[17 * g + k] = rd.fwd_final(x[k]);
   }
   __syncthreads();
   ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(a);
@@ -181,13 +199,16 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     lds[pad(j) + 1] = v.y;
   }
   __syncthreads();
+  ulonglong2 wB[15], wC[15];
 #pragma unroll
   for (int rep = 0; rep < REPS; ++rep) {
     const int g = t + 256 * rep;
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
-    inv_radix<4, RA + 4, 0, FOLD>(x, tw, g, nq, rd);
+    load_twiddles<4, RA + 4>(tw, g, wC);
+    if (rep == REPS - 1) load_twiddles<4, RA>(tw, t >> 4, wB);  // for the next pass (rep 0)
+    inv_radix<4, RA + 4, 0, FOLD>(x, wC, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[17 * g + k] = x[k];
   }
@@ -198,7 +219,8 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
-    inv_radix<4, RA, 4, FOLD>(x, tw, jhi, nq, rd);
+    if (rep > 0) load_twiddles<4, RA>(tw, jhi, wB);
+    inv_radix<4, RA, 4, FOLD>(x, wB, nq, rd);
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
   }
@@ -207,12 +229,13 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     u64 x[EA];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
-    inv_radix<RA, 0, 8, FOLD>(x, tw, 0, nq, rd);
+    ulonglong2 wA[EA - 1];
+    load_twiddles<RA, 0>(tw, 0, wA);
+    inv_radix<RA, 0, 8, FOLD, true>(x, wA, nq, rd);
     const u64 ninv = M.ninv, ninv_sh = M.ninv_sh;
 #pragma unroll
-    for (int k = 0; k < EA; ++k) {
+    for (int k = 0; k < EA; ++k)
       a[k * 256 + t] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
-    }
   }
 }
 
