@@ -92,6 +92,90 @@ def layer_legs(torch, openmm_amd, local):
     return out
 
 
+# ResNet50 linear layers (from networks/main_resnet50.cpp:4981-6333):
+# (C, H, W, fh, fw, M, SAME?, stride, count).  VALID layers arrive pre-padded from the network code.
+RESNET50_CONVS = [
+    (3, 230, 230, 7, 7, 64, 0, 2, 1), (64, 56, 56, 1, 1, 256, 0, 1, 4), (64, 56, 56, 1, 1, 64, 0, 1, 1),
+    (64, 56, 56, 3, 3, 64, 1, 1, 3), (256, 56, 56, 1, 1, 64, 0, 1, 2), (256, 56, 56, 1, 1, 512, 0, 2, 1),
+    (256, 56, 56, 1, 1, 128, 0, 1, 1), (128, 58, 58, 3, 3, 128, 0, 2, 1), (128, 28, 28, 1, 1, 512, 0, 1, 4),
+    (512, 28, 28, 1, 1, 128, 0, 1, 3), (128, 28, 28, 3, 3, 128, 1, 1, 3), (512, 28, 28, 1, 1, 1024, 0, 2, 1),
+    (512, 28, 28, 1, 1, 256, 0, 1, 1), (256, 30, 30, 3, 3, 256, 0, 2, 1), (256, 14, 14, 1, 1, 1024, 0, 1, 6),
+    (1024, 14, 14, 1, 1, 256, 0, 1, 5), (256, 14, 14, 3, 3, 256, 1, 1, 5), (1024, 14, 14, 1, 1, 2048, 0, 2, 1),
+    (1024, 14, 14, 1, 1, 512, 0, 1, 1), (512, 16, 16, 3, 3, 512, 0, 2, 1), (512, 7, 7, 1, 1, 2048, 0, 1, 3),
+    (2048, 7, 7, 1, 1, 512, 0, 1, 2), (512, 7, 7, 3, 3, 512, 1, 1, 2),
+]
+
+
+def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=3):
+    """Second half of BASELINE.json's metric: server-side HE compute of all 53 ResNet50 conv layers
+    + FC 2048->1001 (what CheetahLinear::conv2d / ::fc run between receiving the client's
+    ciphertexts and sending the result, cheetah-api.cpp:417-445, :520-548): filter encoding and
+    lift, image-share encoding, multiply-accumulate, mod-switch, re-share, truncation.  Output
+    filters are sharded over the ranks (hom_conv2d_ss.cc:679-690) and gathered on rank 0; each
+    layer's time is the max over ranks, barrier to barrier.  FC runs replicated (520 products)."""
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    from openmm_amd.hom_fc_ss import HomFCSS, Meta as FcMeta
+    from openmm_amd.sharding import ShardedConv
+    t, N = 1 << 37, 4096
+    ctx = openmm_amd.Context(N, (60, 49), t, device=local)
+    gen = torch.Generator(device="cuda").manual_seed(0x4D264D)  # same inputs on every rank
+    rnd = lambda lo, hi, *shape: torch.randint(lo, hi, shape, dtype=torch.int64, device="cuda", generator=gen)
+    qs = torch.tensor(ctx.q, dtype=torch.int64, device="cuda")
+    pk = rnd(0, 1 << 62, 2, 2, N) % qs.view(1, 2, 1)
+
+    def wall_ms(fn):
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        w = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        return float(w.item())
+
+    srv = HomConv2DSS()
+    srv.setUp(ctx, pk_ntt=pk)
+    per_layer, total = [], 0.0
+    for (c, h, w, fh, fw, m, same, stride, count) in RESNET50_CONVS:
+        shared = c != 3  # first conv runs with kIsSharedInput=false (main_resnet50.cpp:4979)
+        meta = Meta((c, h, w), (c, fh, fw), m, same, stride, shared)
+        sh = ShardedConv(srv, meta) if world > 1 else None
+        plan = srv.plan(meta)
+        cts = rnd(0, 1 << 62, plan.n_in, 2, 2, N) % qs.view(1, 1, 2, 1)
+        share = rnd(0, t, c, h, w)
+        filters = (rnd(-(1 << 12) + 1, 1 << 12, m, c, fh, fw) | 1) & (t - 1)
+        n_out = plan.n_out
+        rand = (rnd(-1, 2, n_out, N), rnd(-8, 9, n_out, N), rnd(0, 1 << 62, n_out, N) % ctx.q[0])
+
+        def layer():
+            s = srv.encodeImage(share, meta) if shared else None
+            if sh is None:
+                return srv.conv2DSS(cts, s, srv.encodeFilters(filters, meta), meta, rand)
+            return sh.run(cts, s, filters, lambda k: tuple(r[:k] for r in rand))
+
+        ms = wall_ms(layer)
+        per_layer.append(round(ms, 3))
+        total += ms * count
+        del cts, share, filters, rand
+    fc = HomFCSS()
+    fc.setUp(ctx, pk_ntt=pk)
+    fmeta = FcMeta((1001, 2048), (2048,), True)
+    fplan = fc.plan(fmeta)
+    vec_ct = rnd(0, 1 << 62, fplan.n_in, 2, 2, N) % qs.view(1, 1, 2, 1)
+    vec, wmat = rnd(0, t, 2048), (rnd(-(1 << 12) + 1, 1 << 12, 1001, 2048) | 1) & (t - 1)
+    frand = (rnd(-1, 2, fplan.n_out, N), rnd(-8, 9, fplan.n_out, N), rnd(0, 1 << 62, fplan.n_out, N) % ctx.q[0])
+    fc_ms = wall_ms(lambda: fc.matVecMul(fc.encodeWeightMatrix(wmat, fmeta), vec_ct,
+                                         fc.encodeInputVector(vec, fmeta), fmeta, frand))
+    return {"resnet50_he_linear_ms": total + fc_ms, "resnet50_conv_layers": 53, "resnet50_fc_ms": round(fc_ms, 3),
+            "resnet50_conv_ms_per_shape": per_layer, "resnet50_sharding": f"output filters x{world}, gather on rank 0"}
+
+
 def timed(fn, steps, warmup, torch, dist, world):
     for _ in range(warmup):
         fn()
@@ -165,7 +249,9 @@ def main():
         if world == 1:
             extra.update(layer_legs(torch, openmm_amd, local))
 
+    net = resnet50_leg(torch, dist, openmm_amd, local, world, rank)
     if rank == 0:
+        extra.update(net)
         line = {
             "metric": "64-bit NTTs/sec (N=4096/8192) + ResNet50 HE-linear ms at 1/2/4/8 GPUs",
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,

@@ -8,6 +8,8 @@
 namespace mmh {
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
                  int mod_base, hipStream_t s);
+int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
+                      hipStream_t s);
 
 // stream-ordered scratch buffer
 struct StreamBuf {
@@ -38,16 +40,6 @@ __global__ __launch_bounds__(256) void add_plain_kernel(u64 *__restrict__ cts, c
     u64 *d = cts + (((k * 2) * c.limbs + l) << logN) + i;
     *d = sub ? sub_mod(*d, s, q.q) : add_mod(*d, s, q.q);
   }
-}
-
-__global__ __launch_bounds__(256) void plain_lift_kernel(const u64 *__restrict__ pts, u64 *__restrict__ out,
-                                                         size_t total, int logN, int limbs, u64 t, u64 thr,
-                                                         const DevMod *__restrict__ mods) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
-  const u64 m = pts[idx];
-  for (int l = 0; l < limbs; ++l) out[((k * limbs + l) << logN) + i] = m >= thr ? m + (mods[l].q - t) : m;
 }
 
 // out[o1][o2] = sum_k ct[...] (.) pt[...], TM outputs along o1 per thread so that each ct
@@ -341,9 +333,7 @@ extern "C" int mmh_plain_lift_ntt(const mmh_ctx *ctx, int lv, const uint64_t *d_
   MMH_REQUIRE(d_pts && d_out, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   const int limbs = limbs_of(ctx, lv);
-  LAUNCH(plain_lift_kernel, n * ctx->N, s, d_pts, d_out, n * ctx->N, ctx->logN, limbs, ctx->t, ctx->bfv.thr,
-         ctx->d_mods);
-  return ntt_dispatch(ctx, false, d_out, n, limbs, 0, s);
+  return ntt_lift_dispatch(ctx, d_pts, d_out, n, limbs, s);  // lift fused into the transform's load
 }
 
 extern "C" int mmh_dyadic_mac(const mmh_ctx *ctx, int lv, const uint64_t *d_cts_ntt, size_t n_cts,

@@ -116,11 +116,16 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 (&t
   }
 }
 
-template <int LOGN, bool FOLD>
+// LIFT: the input is not `data` itself but plaintext `src` [n_polys][N] with coefficients mod t,
+// lifted on load into every limb the way multiply_plain does (m >= (t+1)/2 -> m + (q - t)); the
+// lifted polynomials never exist in memory.
+template <int LOGN, bool FOLD, bool LIFT = false>
 __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
-                                                      int limbs, int mod_base) {
+                                                      int limbs, int mod_base,
+                                                      const u64 *__restrict__ src, u64 plain_t,
+                                                      u64 plain_thr) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
@@ -133,8 +138,17 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   ulonglong2 wB[15], wC[15];
   {
     u64 x[EA];
+    if (LIFT) {
+      const u64 *__restrict__ m = src + (size_t)(blockIdx.x / limbs) * N;
+      const u64 up = M.q - plain_t;
 #pragma unroll
-    for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
+      for (int k = 0; k < EA; ++k) x[k] = m[k * 256 + t];
+#pragma unroll
+      for (int k = 0; k < EA; ++k) x[k] += x[k] >= plain_thr ? up : 0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
+    }
     ulonglong2 wA[EA - 1];
     load_twiddles<RA, 0>(tw, 0, wA);          // wave-uniform: scalar loads
     load_twiddles<4, RA>(tw, t >> 4, wB);     // for pass B (rep 0), in flight during pass A
@@ -180,7 +194,7 @@ template <int LOGN, bool FOLD>
 __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
-                                                      int limbs, int mod_base) {
+                                                      int limbs, int mod_base, const u64 *, u64, u64) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
@@ -244,32 +258,45 @@ static constexpr size_t lds_bytes() {
   return ((size_t(1) << LOGN) + (size_t(1) << (LOGN - 4))) * sizeof(u64);
 }
 
+// mode 0 forward in place, 1 inverse in place, 2 forward from plaintext `src` lifted on load
 template <int LOGN>
-static int launch(bool inverse, bool fold, u64 *d, const DevMod *mods, const ulonglong2 *tables, size_t blocks,
-                  int limbs, int mod_base, hipStream_t s) {
-  auto kern = inverse ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
-                      : (fold ? ntt_fwd_kernel<LOGN, true> : ntt_fwd_kernel<LOGN, false>);
+static int launch(int mode, bool fold, u64 *d, const mmh_ctx *ctx, size_t blocks, int limbs, int mod_base,
+                  const u64 *src, hipStream_t s) {
+  auto kern = mode == 1   ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
+              : mode == 2 ? (fold ? ntt_fwd_kernel<LOGN, true, true> : ntt_fwd_kernel<LOGN, false, true>)
+                          : (fold ? ntt_fwd_kernel<LOGN, true, false> : ntt_fwd_kernel<LOGN, false, false>);
   if (lds_bytes<LOGN>() > 48 * 1024)  // per device and cheap: set on every launch
     MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<LOGN>()));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes<LOGN>(), s, d, mods, tables,
-                     limbs, mod_base);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes<LOGN>(), s, d, ctx->d_mods,
+                     ctx->d_tables, limbs, mod_base, src, ctx->t, ctx->bfv.thr);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
 
-int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
-                 int mod_base, hipStream_t s) {
+static int dispatch(const mmh_ctx *ctx, int mode, u64 *d, const u64 *src, size_t n_polys, int limbs, int mod_base,
+                    hipStream_t s) {
   const size_t blocks = n_polys * (size_t)limbs;
   if (blocks == 0) return MMH_OK;
   MMH_REQUIRE(blocks <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
   bool fold = true;  // every modulus of this launch must have the 2^b - c shape for the fast reducer
   for (int l = 0; l < limbs; ++l) fold = fold && ctx->h_mods[mod_base + l].fold_c != 0;
   switch (ctx->logN) {
-    case 12: return launch<12>(inverse, fold, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
-    case 13: return launch<13>(inverse, fold, d_polys, ctx->d_mods, ctx->d_tables, blocks, limbs, mod_base, s);
+    case 12: return launch<12>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s);
+    case 13: return launch<13>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s);
     default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
   }
+}
+
+// out[k][l] = NTT_l(lift_l(src[k])) for the first `limbs` moduli, src [n_polys][N] mod t
+int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
+                      hipStream_t s) {
+  return dispatch(ctx, 2, d_out, d_src, n_polys, limbs, 0, s);
+}
+
+int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
+                 int mod_base, hipStream_t s) {
+  return dispatch(ctx, inverse ? 1 : 0, d_polys, nullptr, n_polys, limbs, mod_base, s);
 }
 }  // namespace mmh
 

@@ -14,6 +14,12 @@ from . import lib as L
 VALID, SAME = 0, 1  # gemini::Padding (tensor_shape.h:11)
 
 
+def _mod_t(x, t):
+    """int64 tensor holding uint64 bits, reduced mod t (power of two: mask; else torch remainder on
+    the non-negative representatives the callers pass)"""
+    return x & (t - 1) if t & (t - 1) == 0 else x % t
+
+
 class ConvMetaC(C.Structure):
     _fields_ = [("in_c", C.c_int64), ("in_h", C.c_int64), ("in_w", C.c_int64), ("f_h", C.c_int64),
                 ("f_w", C.c_int64), ("n_filters", C.c_int64), ("padding_same", C.c_int32),
@@ -109,6 +115,9 @@ class HomConv2DSS:
         p = self.plan(meta)
         out = self.ctx._empty(meta.n_filters, p.n_cslices, self.ctx.N)
         L.check(self.ctx.lib.mmh_conv_encode_filters(p.handle, L.dptr(filters), L.dptr(out), L._stream_ptr()))
+        # a filter encodes to all-zero polynomials iff all its weights are 0 mod t: settle the
+        # conv2DOneFilter :573-580 check here, on the small tensor, and remember the verdict
+        out._mm_nonzero = bool((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
         return out
 
     # conv2DSS (hom_conv2d_ss.cc:621-712); rand = (u [n_out,N], e1 [n_out,N], mask [n_out,N])
@@ -120,8 +129,10 @@ class HomConv2DSS:
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
         # conv2DOneFilter :573-580: a filter whose polynomials are all zero is an error
-        nz = (filters.reshape(meta.n_filters, -1) != 0).any(dim=1)
-        self._need(bool(nz.all()), 8, "conv2DOneFilter: filter with all zero is not supported")
+        nz = getattr(filters, "_mm_nonzero", None)
+        if nz is None:  # polynomials that did not come from encodeFilters: look at them
+            nz = bool((filters.reshape(meta.n_filters, -1) != 0).any(dim=1).all())
+        self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
         u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)

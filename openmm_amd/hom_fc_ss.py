@@ -81,6 +81,12 @@ class HomFCSS:
         p = self.plan(meta)
         out = self.ctx._empty(p.n_out, p.n_in, self.ctx.N)
         L.check(self.ctx.lib.mmh_fc_encode_weights(p.handle, L.dptr(w), L.dptr(out), L._stream_ptr()))
+        # :414-422 rejects a d0 x d1 block that encodes to zero; decide on the raw matrix (small)
+        import torch.nn.functional as F
+        from .hom_conv2d_ss import _mod_t
+        d0, d1 = p.split
+        nz = F.pad(_mod_t(w, self.ctx.t) != 0, (0, p.n_in * d1 - w.shape[1], 0, p.n_out * d0 - w.shape[0]))
+        out._mm_nonzero = bool(nz.view(p.n_out, d0, p.n_in, d1).any(dim=3).any(dim=1).all())
         return out
 
     def matVecMul(self, matrix, vec_share0, vec_share1, meta, rand):  # :394-471
@@ -89,7 +95,10 @@ class HomFCSS:
         self._need(vec_share0.shape[0] == p.n_in, 7, "matVecMul: #input ciphertexts")
         self._need(tuple(matrix.shape[:2]) == (p.n_out, p.n_in), 7, "matVecMul: #weight blocks")
         # :414-422: a sub-matrix that encodes to zero is rejected
-        self._need(bool((matrix != 0).any(dim=2).all()), 7, "matVecMul: sub-matrix with all zero is not supported")
+        nz = getattr(matrix, "_mm_nonzero", None)
+        if nz is None:
+            nz = bool((matrix != 0).any(dim=2).all())
+        self._need(nz, 7, "matVecMul: sub-matrix with all zero is not supported")
         if meta.is_shared_input:
             self._need(vec_share1 is not None and vec_share1.shape[0] == p.n_in, 3, "matVecMul: #shares")
         u, e1, mask = rand
