@@ -240,6 +240,15 @@ int mmh_conv_server(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const u
                     const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                     const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
                     void *stream);
+/* The server half of CheetahLinear::conv2d in one call (cheetah-api.cpp:417-445: encodeFilters
+ * followed by conv2DSS): as mmh_conv_server but from the raw filters d_filters [M][C][fh][fw].
+ * Each filter polynomial is encoded, lifted and transformed on chip, so the sparse plaintexts of
+ * mmh_conv_encode_filters are never written; results are bit-identical to the two-call form.
+ * The caller keeps the conv2DOneFilter :573-580 rule (a filter that is all zero mod t is an error). */
+int mmh_conv_server_weights(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                            const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                            const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                            uint64_t *d_out_share, void *stream);
 /* HomConv2DSS::decryptToTensor (hom_conv2d_ss.cc:853-941): d_sk_ntt at the last level [1][N] */
 int mmh_conv_decrypt(const mmh_conv_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
                      uint64_t *d_out, void *stream);

@@ -60,22 +60,43 @@ __global__ __launch_bounds__(256) void dyadic_mac_kernel(const u64 *__restrict__
   u64 lo[TM][2], hi[TM][2];
 #pragma unroll
   for (int j = 0; j < TM; ++j) lo[j][0] = lo[j][1] = hi[j][0] = hi[j][1] = 0;
+  // operands of term k+1 are fetched while term k is multiplied: the loop is a pure stream over
+  // the plaintext operand and needs the next loads in flight to cover the HBM latency
+  const u64 *ct_ptr = cts + ((o2 * ct_s2 * 2) * limbs + l) * poly + i;
+  const size_t ct_step = ct_sk * 2 * limbs * poly, c1_off = (size_t)limbs * poly;
+  const u64 *pt_ptr[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const unsigned o1 = o1_base + j < n_o1 ? o1_base + j : n_o1 - 1;  // tail lanes repeat the last filter
+    pt_ptr[j] = pts + ((o1 * pt_s1 + o2 * pt_s2) * limbs + l) * poly + i;
+  }
+  const size_t pt_step = pt_sk * limbs * poly;
+  u64 c0n = ct_ptr[0], c1n = ct_ptr[c1_off], wn[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) wn[j] = pt_ptr[j][0];
   for (unsigned k = 0; k < K; ++k) {
-    const size_t ct = k * ct_sk + o2 * ct_s2;
-    const u64 c0 = cts[((ct * 2 + 0) * limbs + l) * poly + i];
-    const u64 c1 = cts[((ct * 2 + 1) * limbs + l) * poly + i];
+    const u64 c0 = c0n, c1 = c1n;
+    u64 w[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) w[j] = wn[j];
+    if (k + 1 < K) {
+      ct_ptr += ct_step;
+      c0n = ct_ptr[0];
+      c1n = ct_ptr[c1_off];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        pt_ptr[j] += pt_step;
+        wn[j] = pt_ptr[j][0];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      if (o1_base + j < n_o1) {
-        const size_t pt = (o1_base + j) * pt_s1 + k * pt_sk + o2 * pt_s2;
-        const u64 w = pts[(pt * limbs + l) * poly + i];
-        u64 p = c0 * w;
-        lo[j][0] += p;
-        hi[j][0] += mulhi64(c0, w) + (lo[j][0] < p);
-        p = c1 * w;
-        lo[j][1] += p;
-        hi[j][1] += mulhi64(c1, w) + (lo[j][1] < p);
-      }
+      u64 p = c0 * w[j];
+      lo[j][0] += p;
+      hi[j][0] += mulhi64(c0, w[j]) + (lo[j][0] < p);
+      p = c1 * w[j];
+      lo[j][1] += p;
+      hi[j][1] += mulhi64(c1, w[j]) + (lo[j][1] < p);
     }
     // Barrett's 64-bit quotient needs the sum below q*2^64: 8 products of < q^2 with q < 2^61
     if ((k & 7) == 7) {

@@ -9,6 +9,11 @@
 namespace mmh {
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
                  int mod_base, hipStream_t s);
+int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
+                      hipStream_t s);
+int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
+                        int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
+                        hipStream_t s);
 
 // one input window (image polynomial): where it reads the strided image and its zero margins
 struct ImgWindow {
@@ -303,34 +308,48 @@ extern "C" int mmh_conv_encrypt_image(const mmh_conv_plan *p, const uint64_t *d_
   return rc;
 }
 
-extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
-                               const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
-                               const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
-                               uint64_t *d_out_share, void *stream) {
-  MMH_REQUIRE(p && d_in_cts && d_filter_pts && d_pk_ntt_last && d_u && d_e1 && d_mask && d_out_cts && d_out_share,
+// conv2DSS for all filters.  Exactly one of d_filter_pts (encoded plaintexts, [M*Cs][N]) and
+// d_filters_raw ([M][C][fh][fw]) is given; both produce the same bits.
+static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                            const uint64_t *d_filter_pts, const uint64_t *d_filters_raw,
+                            const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
+                            const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw) && d_pk_ntt_last && d_u && d_e1 && d_mask &&
+                  d_out_cts && d_out_share,
               MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
   const mmh_ctx *ctx = p->ctx;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
-  void *image = nullptr, *acc = nullptr, *zero = nullptr;
+  void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr;
   int rc = MMH_OK;
   auto cleanup = [&]() {
-    if (image) (void)hipFreeAsync(image, s);
-    if (acc) (void)hipFreeAsync(acc, s);
-    if (zero) (void)hipFreeAsync(zero, s);
+    for (void *b : {image, acc, zero, f_ntt})
+      if (b) (void)hipFreeAsync(b, s);
   };
-  const u64 *cts = d_in_cts;
-  if (p->meta.is_shared_input) {  // conv2DSS :655-671: image = share0 + Delta*share1
-    MMH_HIP(hipMallocAsync(&image, p->n_in * 4 * N * 8, s));
-    rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
-    cts = (const u64 *)image;
-  }
-  if (!rc && hipMallocAsync(&acc, p->n_out * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
-  if (!rc && hipMallocAsync(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  auto grab = [&](void **b, size_t bytes) {
+    if (!rc && hipMallocAsync(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  };
+  grab(&image, p->n_in * 4 * N * 8);
+  grab(&acc, p->n_out * 4 * N * 8);
+  grab(&zero, p->n_out * 2 * N * 8);
+  grab(&f_ntt, M * Cs * 2 * N * 8);
+  // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
+  if (!rc && p->meta.is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
+  if (!rc && !p->meta.is_shared_input &&
+      hipMemcpyAsync(image, d_in_cts, p->n_in * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    rc = MMH_ERR_INTERNAL;
+  if (!rc) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
+  // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
+  if (!rc && d_filters_raw)
+    rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
+                             (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
+                             p->split.win_w, 2, s);
+  if (!rc && !d_filters_raw) rc = ntt_lift_dispatch(ctx, d_filter_pts, (u64 *)f_ntt, M * Cs, 2, s);
   // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
-  if (!rc) rc = mmh_mul_plain_acc(ctx, 0, cts, p->n_in, d_filter_pts, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
+  if (!rc) rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, (const u64 *)f_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
+  if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
   // addRandomMask :761-788: flood_ciphertext (mod-switch + pk-encryption of zero without e0),
   if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
   if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, nullptr, d_e1, p->n_out, (u64 *)zero, stream);
@@ -344,6 +363,25 @@ extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts,
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, S, stream);
   cleanup();
   return rc;
+}
+
+extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                               const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                               const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                               uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(d_filter_pts, MMH_ERR_NULL_POINTER);
+  return conv_server_impl(p, d_in_cts, d_share_pts, d_filter_pts, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask,
+                          d_out_cts, d_out_share, stream);
+}
+
+extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d_in_cts,
+                                       const uint64_t *d_share_pts, const uint64_t *d_filters,
+                                       const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
+                                       const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
+                                       void *stream) {
+  MMH_REQUIRE(d_filters, MMH_ERR_NULL_POINTER);
+  return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask,
+                          d_out_cts, d_out_share, stream);
 }
 
 extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,

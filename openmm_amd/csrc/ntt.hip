@@ -116,16 +116,30 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 (&t
   }
 }
 
-// LIFT: the input is not `data` itself but plaintext `src` [n_polys][N] with coefficients mod t,
-// lifted on load into every limb the way multiply_plain does (m >= (t+1)/2 -> m + (q - t)); the
-// lifted polynomials never exist in memory.
-template <int LOGN, bool FOLD, bool LIFT = false>
+// Where a forward transform takes its input from.
+//   SRC_INPLACE  `data` itself.
+//   SRC_PLAIN    plaintext `src.p` [n_polys][N] with coefficients mod t, lifted on load into every
+//                limb the way multiply_plain does (m >= (t+1)/2 -> m + (q - t)); the lifted
+//                polynomials never exist in memory.
+//   SRC_FILTER   raw conv filters `src.p` [M][C][fh][fw]: polynomial (m, slice) is encoded on chip
+//                (tensor_encoder.cc EncodeFilter: tap (cc, r, col) -> coefficient
+//                origin - cc*plane - r*row - col), so neither the sparse plaintexts nor their
+//                lifted images exist in memory.
+enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2 };
+struct NttSource {
+  const u64 *p;
+  u64 t, thr;                      // plain modulus and the lift threshold (t + 1) / 2
+  u64 t_bhi, t_blo;                // Barrett constants of t (SRC_FILTER reduces the raw weights)
+  int C, taps, wc, n_cslices;      // channels, fh*fw, channels per slice, slices per filter
+  int fw, origin, plane, row;      // coefficient = origin - cc*plane - r*row - col
+};
+
+template <int LOGN, bool FOLD, int SRC = SRC_INPLACE>
 __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
                                                       int limbs, int mod_base,
-                                                      const u64 *__restrict__ src, u64 plain_t,
-                                                      u64 plain_thr) {
+                                                      NttSource src) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
@@ -138,13 +152,30 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   ulonglong2 wB[15], wC[15];
   {
     u64 x[EA];
-    if (LIFT) {
-      const u64 *__restrict__ m = src + (size_t)(blockIdx.x / limbs) * N;
-      const u64 up = M.q - plain_t;
+    if (SRC == SRC_PLAIN) {
+      const u64 *__restrict__ m = src.p + (size_t)(blockIdx.x / limbs) * N;
+      const u64 up = M.q - src.t;
 #pragma unroll
       for (int k = 0; k < EA; ++k) x[k] = m[k * 256 + t];
 #pragma unroll
-      for (int k = 0; k < EA; ++k) x[k] += x[k] >= plain_thr ? up : 0;
+      for (int k = 0; k < EA; ++k) x[k] += x[k] >= src.thr ? up : 0;
+    } else if (SRC == SRC_FILTER) {
+      const int poly = blockIdx.x / limbs, fm = poly / src.n_cslices, slice = poly % src.n_cslices;
+      const int nch = min(src.wc, src.C - slice * src.wc);
+      const u64 *__restrict__ taps = src.p + ((size_t)fm * src.C + (size_t)slice * src.wc) * src.taps;
+      const u64 up = M.q - src.t;
+#pragma unroll
+      for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = 0;
+      __syncthreads();
+      for (int i = t; i < nch * src.taps; i += 256) {
+        const int cc = i / src.taps, rc = i % src.taps, r = rc / src.fw, col = rc % src.fw;
+        u64 v = barrett128(0, taps[i], src.t, src.t_bhi, src.t_blo);
+        v += v >= src.thr ? up : 0;
+        lds[pad(src.origin - cc * src.plane - r * src.row - col)] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
     } else {
 #pragma unroll
       for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
@@ -194,7 +225,7 @@ template <int LOGN, bool FOLD>
 __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
-                                                      int limbs, int mod_base, const u64 *, u64, u64) {
+                                                      int limbs, int mod_base, NttSource) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
@@ -258,24 +289,27 @@ static constexpr size_t lds_bytes() {
   return ((size_t(1) << LOGN) + (size_t(1) << (LOGN - 4))) * sizeof(u64);
 }
 
-// mode 0 forward in place, 1 inverse in place, 2 forward from plaintext `src` lifted on load
+// mode: SRC_* for a forward transform, -1 for the inverse (in place)
 template <int LOGN>
 static int launch(int mode, bool fold, u64 *d, const mmh_ctx *ctx, size_t blocks, int limbs, int mod_base,
-                  const u64 *src, hipStream_t s) {
-  auto kern = mode == 1   ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
-              : mode == 2 ? (fold ? ntt_fwd_kernel<LOGN, true, true> : ntt_fwd_kernel<LOGN, false, true>)
-                          : (fold ? ntt_fwd_kernel<LOGN, true, false> : ntt_fwd_kernel<LOGN, false, false>);
+                  const NttSource &src, hipStream_t s) {
+  auto kern = mode < 0 ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
+              : mode == SRC_PLAIN
+                  ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_PLAIN> : ntt_fwd_kernel<LOGN, false, SRC_PLAIN>)
+              : mode == SRC_FILTER
+                  ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_FILTER> : ntt_fwd_kernel<LOGN, false, SRC_FILTER>)
+                  : (fold ? ntt_fwd_kernel<LOGN, true, SRC_INPLACE> : ntt_fwd_kernel<LOGN, false, SRC_INPLACE>);
   if (lds_bytes<LOGN>() > 48 * 1024)  // per device and cheap: set on every launch
     MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<LOGN>()));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes<LOGN>(), s, d, ctx->d_mods,
-                     ctx->d_tables, limbs, mod_base, src, ctx->t, ctx->bfv.thr);
+                     ctx->d_tables, limbs, mod_base, src);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
 
-static int dispatch(const mmh_ctx *ctx, int mode, u64 *d, const u64 *src, size_t n_polys, int limbs, int mod_base,
-                    hipStream_t s) {
+static int dispatch(const mmh_ctx *ctx, int mode, u64 *d, const NttSource &src, size_t n_polys, int limbs,
+                    int mod_base, hipStream_t s) {
   const size_t blocks = n_polys * (size_t)limbs;
   if (blocks == 0) return MMH_OK;
   MMH_REQUIRE(blocks <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
@@ -291,12 +325,30 @@ static int dispatch(const mmh_ctx *ctx, int mode, u64 *d, const u64 *src, size_t
 // out[k][l] = NTT_l(lift_l(src[k])) for the first `limbs` moduli, src [n_polys][N] mod t
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s) {
-  return dispatch(ctx, 2, d_out, d_src, n_polys, limbs, 0, s);
+  NttSource src{};
+  src.p = d_src, src.t = ctx->t, src.thr = ctx->bfv.thr;
+  return dispatch(ctx, SRC_PLAIN, d_out, src, n_polys, limbs, 0, s);
+}
+
+// out[m*n_cslices + slice][l] = NTT_l(lift_l(EncodeFilter(filters[m], slice))), filters [M][C][fh][fw]
+int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
+                        int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
+                        hipStream_t s) {
+  // every tap must land inside the polynomial: largest index is origin, smallest origin - span
+  const long span = (long)(wc - 1) * plane + (long)(fh - 1) * row + (fw - 1);
+  MMH_REQUIRE(origin < (long)ctx->N && origin - span >= 0 && wc >= 1 && n_cslices >= 1, MMH_ERR_OUT_BOUND);
+  MMH_REQUIRE((long)(n_cslices - 1) * wc < C && (long)n_cslices * wc >= C, MMH_ERR_OUT_BOUND);
+  NttSource src{};
+  src.p = d_filters, src.t = ctx->t, src.thr = ctx->bfv.thr;
+  src.t_bhi = ctx->bfv.t.barrett_hi, src.t_blo = ctx->bfv.t.barrett_lo;
+  src.C = C, src.taps = fh * fw, src.wc = wc, src.n_cslices = n_cslices;
+  src.fw = fw, src.origin = (int)origin, src.plane = (int)plane, src.row = (int)row;
+  return dispatch(ctx, SRC_FILTER, d_out, src, n_filters * (size_t)n_cslices, limbs, 0, s);
 }
 
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
                  int mod_base, hipStream_t s) {
-  return dispatch(ctx, inverse ? 1 : 0, d_polys, nullptr, n_polys, limbs, mod_base, s);
+  return dispatch(ctx, inverse ? -1 : SRC_INPLACE, d_polys, NttSource{}, n_polys, limbs, mod_base, s);
 }
 }  // namespace mmh
 

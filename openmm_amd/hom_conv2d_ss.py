@@ -142,6 +142,28 @@ class HomConv2DSS:
                                              L.dptr(mask), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
         return out_cts, out_share
 
+    # encodeFilters + conv2DSS as CheetahLinear::conv2d chains them (cheetah-api.cpp:417-445), in one
+    # device call from the raw filters [M, C, fh, fw]; bit-identical to the two-call form
+    def conv2DSSFromWeights(self, img_share0, img_share1, filters, meta, rand):
+        self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
+        self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
+        self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
+        p = self.plan(meta)
+        self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
+        if meta.is_shared_input:
+            self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
+        nz = bool((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
+        self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
+        u, e1, mask = rand
+        out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
+        out_share = self.ctx._empty(*p.out_shape)
+        L.check(self.ctx.lib.mmh_conv_server_weights(p.handle, L.dptr(img_share0),
+                                                     L.dptr(img_share1 if meta.is_shared_input else None),
+                                                     L.dptr(filters.contiguous()), L.dptr(self.pk_last), L.dptr(u),
+                                                     L.dptr(e1), L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
+                                                     L._stream_ptr()))
+        return out_cts, out_share
+
     # decryptToTensor (hom_conv2d_ss.cc:853-941)
     def decryptToTensor(self, enc_tensor, meta):
         self._need(self.sk_ntt is not None, 1, "decrypt without sk")

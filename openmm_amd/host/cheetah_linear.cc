@@ -224,9 +224,8 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
       for (size_t i = 0; i < f_words && !nz; ++i) nz = (fh[k * f_words + i] % base_mod_) != 0;
       if (!nz) throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
     }
-    Dev dfilt(fh.size()), fpts(meta.n_filters * n_cs * N), spts;
+    Dev dfilt(fh.size()), spts;
     dfilt.upload(fh.data(), fh.size());
-    must(mmh_conv_encode_filters(plan, dfilt.p, fpts.p, nullptr), "CheetahLinear::conv2d ecnodeFilters");
     if (meta.is_shared_input) {
       spts.alloc(n_in * N);
       must(mmh_conv_encode_image(plan, img.p, spts.p, nullptr), "CheetahLinear::conv2d encodeImage");
@@ -234,8 +233,9 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
     Dev cts = I.recv_cts(n_in, 2 * L * N);
     Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
     Dev out_cts(n_out * 2 * N), share(out_words);
-    must(mmh_conv_server(plan, cts.p, spts.p, fpts.p, I.ring.pk_last.p, (const int64_t *)u.p, (const int64_t *)e1.p,
-                         mask.p, out_cts.p, share.p, nullptr),
+    // encodeFilters + conv2DSS (cheetah-api.cpp:417-445) in one device call
+    must(mmh_conv_server_weights(plan, cts.p, spts.p, dfilt.p, I.ring.pk_last.p, (const int64_t *)u.p,
+                                 (const int64_t *)e1.p, mask.p, out_cts.p, share.p, nullptr),
          "CheetahLinear::conv2d conv2DSS:");
     share.download(out_tensor.data(), out_words);
     I.send_cts(out_cts, n_out, 2 * N);

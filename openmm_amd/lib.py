@@ -70,6 +70,7 @@ SIGNATURES = {
     "mmh_conv_encode_filters": [_vp, _vp, _vp, _vp],
     "mmh_conv_encrypt_image": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],
     "mmh_fc_plan_destroy": [_vp],

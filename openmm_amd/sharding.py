@@ -55,8 +55,9 @@ class ShardedConv:
         full = self.server.plan(self.meta)
         n_sp = full.n_spatial
         if n_local > 0:
-            f = self.server.encodeFilters(filters[self.lo:self.hi].contiguous(), self.local_meta)
-            cts, share = self.server.conv2DSS(img_share0, img_share1, f, self.local_meta, rand_for(n_local * n_sp))
+            cts, share = self.server.conv2DSSFromWeights(img_share0, img_share1,
+                                                         filters[self.lo:self.hi].contiguous(), self.local_meta,
+                                                         rand_for(n_local * n_sp))
             cts = cts.reshape(n_local, n_sp, *cts.shape[1:])
         else:  # more ranks than filters: nothing to do, contribute an empty slice
             ref = img_share0

@@ -83,6 +83,10 @@ def test_conv_layer_bit_exact(mm, ishape, fhw, M, same, stride, shared):
     got_out, got_share = server.conv2DSS(got_cts, got_s, got_f, meta, (dev(u), dev(e1), dev(mask)))
     assert np.array_equal(host(got_out), ref_out)
     assert np.array_equal(host(got_share), ref_share)
+    # the one-call form from the raw filters (encode + lift + NTT on chip) gives the same bits
+    one_out, one_share = server.conv2DSSFromWeights(got_cts, got_s, dev(filters), meta, (dev(u), dev(e1), dev(mask)))
+    assert np.array_equal(host(one_out), ref_out)
+    assert np.array_equal(host(one_share), ref_share)
     # client: decryptToTensor, then the reference's acceptance identity
     ref_dec = cv.decrypt(np.ascontiguousarray(sk[:1]), ref_out)
     got_dec = host(client.decryptToTensor(got_out, meta))

@@ -32,7 +32,8 @@ class FakeServer:
         assert filters.shape[0] == meta.n_filters
         return filters
 
-    def conv2DSS(self, s0, s1, f, meta, rand):
+    def conv2DSSFromWeights(self, s0, s1, f, meta, rand):
+        assert f.shape[0] == meta.n_filters
         m = f.shape[0]
         key = f.reshape(m, -1).sum(1)
         cts = (key[:, None, None] * 7 + torch.arange(self.P.n_spatial)[None, :, None] + rand[0]).expand(m, 3, 8)
@@ -58,7 +59,7 @@ def _worker(rank, world, port, n_filters, q):
         x = torch.arange(1000, dtype=torch.int64)
         y = sharded_elementwise(lambda t: t * 3 + 1, x)
         if rank == 0:
-            ref_cts, ref_share = srv.conv2DSS(s0, s0, filters, meta, (5,))
+            ref_cts, ref_share = srv.conv2DSSFromWeights(s0, s0, filters, meta, (5,))
             q.put((torch.equal(cts, ref_cts), torch.equal(share, ref_share), torch.equal(y, x * 3 + 1)))
         else:
             assert cts is None and share is None and y is None
