@@ -60,6 +60,9 @@ class CheetahLinear {
           Tensor<uint64_t> &out_vector) const;
   void BOLE(const Tensor<uint64_t> &input_x_vector, const Tensor<uint64_t> &input_y_vector, const BNMeta &meta,
             Tensor<uint64_t> &out_vector) const;
+  // cheetah-api.h: channel-wise scaling of a C x H x W tensor mod base_mod (meta.ishape), coefficient-packed
+  void bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor<uint64_t> &scale_vector, const BNMeta &meta,
+                 Tensor<uint64_t> &out_tensor) const;
 
   uint64_t io_counter() const { return io_ ? io_->counter : 0; }
   int party() const { return party_; }

@@ -309,6 +309,40 @@ int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, const uint64_t
 int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n,
                           uint64_t *d_out, void *stream);
 
+/* -------------------------------------------------------------------------------------
+ * HomBNSS direct path (hom_bn_ss.cc:471-790, the BatchNorm() wrapper of
+ * library_fixed_uniform_cheetah.cpp:465): a C x H x W tensor mod t = 2^k is coefficient-packed in
+ * floor(sqrt(N))-square tiles, one channel per tile (getSplitBN :61-67), and every channel is
+ * multiplied by a signed scalar.  Ciphertext cid = (c*dH + hb)*dW + wb.
+ * ------------------------------------------------------------------------------------- */
+typedef struct mmh_bn_tensor_meta {
+  int64_t c, h, w;          /* HomBNSS::Meta::ishape */
+  int32_t is_shared_input;
+} mmh_bn_tensor_meta;
+/* number of plaintexts / ciphertexts dC*dH*dW and the tile shape {1, sh, sw} */
+int mmh_bn_tensor_count(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, size_t *n_cts, int64_t split[3]);
+/* HomBNSS::encodeTensor (:471-520): entry (h, w) of a tile at coefficient h*sw + w, zero outside */
+int mmh_bn_encode_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_tensor,
+                         uint64_t *d_pts, void *stream);
+/* HomBNSS::encryptTensor (:522-576) with injected randomness d_a [n][L][N], d_e [n][N] */
+int mmh_bn_encrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_sk_ntt,
+                          const uint64_t *d_tensor, const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts,
+                          void *stream);
+/* HomBNSS::bn_direct (:578-738): add_plain of the server's share (d_share_pts NULL unless
+ * is_shared_input), multiply_poly_scalar_coeffmod by (+/-)(|scales[c]| mod t) (scales read as
+ * int64), mod-switch, sub_plain of encodeTensor(d_share1), add Encryptor::encrypt_zero at the last
+ * level (a first-level pk encryption with u, e0, e1 [n][N] that is mod-switched; d_pk_ntt is the
+ * full key [2][L][N]), remove_unused_coeffs on the first vh*vw coefficients, truncate_for_decryption.
+ * d_share1 [C][H][W] is the server's output share, already uniform mod t (the reference draws it
+ * at :712-723); outputs d_out_cts [n][2][1][N]. */
+int mmh_bn_direct_server(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_in_cts,
+                         const uint64_t *d_share_pts, const uint64_t *d_scales, const uint64_t *d_pk_ntt,
+                         const int64_t *d_u, const int64_t *d_e0, const int64_t *d_e1, const uint64_t *d_share1,
+                         uint64_t *d_out_cts, void *stream);
+/* HomBNSS::decryptToTensor (:740-790): valid entries of each tile from consecutive coefficients */
+int mmh_bn_decrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_sk_ntt,
+                          const uint64_t *d_cts, uint64_t *d_out, void *stream);
+
 /* =====================================================================================
  * Modulus conversion: local share arithmetic of SCI's Truncation class
  * (SCI/src/BuildingBlocks/truncation.h:29-210), split around its single COT call.

@@ -379,3 +379,188 @@ extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
   if (slots) (void)hipFreeAsync(slots, s);
   return rc;
 }
+
+// ------------------------------------------------------------------- HomBNSS, direct path
+// Coefficient-packed per-channel scaling (hom_bn_ss.cc:471-790).  getSplitBN :61-67 never splits
+// channels: tile (c, hb, wb) of floor(sqrt(N))-sized squares holds entry (h, w) at coefficient
+// h*sw + w, zero where the tile sticks out of the tensor.  The re-sharing and decrypt sides index
+// the *valid* entries of a tile densely instead (0 .. vh*vw-1, :666-678 and :769-781); both agree
+// with the encoder only when no tile is ragged in w.  Restated as written.
+namespace mmh {
+struct BnTiles {
+  long C, H, W, sh, sw, dH, dW;
+  size_t n_ct;
+};
+
+__global__ __launch_bounds__(256) void bn_tensor_encode_kernel(const u64 *__restrict__ tensor,
+                                                               u64 *__restrict__ polys, size_t total, int logN,
+                                                               BnTiles g, ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long cid = (long)(idx >> logN), i = (long)(idx & ((size_t(1) << logN) - 1));
+  u64 v = 0;
+  if (i < g.sh * g.sw) {
+    const long c = cid / (g.dH * g.dW), hh = (cid / g.dW) % g.dH * g.sh + i / g.sw, ww = cid % g.dW * g.sw + i % g.sw;
+    if (hh < g.H && ww < g.W) v = barrett128(0, tensor[(c * g.H + hh) * g.W + ww], t.q, t.barrett_hi, t.barrett_lo);
+  }
+  polys[idx] = v;
+}
+
+// bn_direct :613-645: every polynomial of channel c times (+/-)(|scales[c]| mod t) mod q_l
+__global__ __launch_bounds__(256) void bn_scale_kernel(u64 *__restrict__ cts, const u64 *__restrict__ scales,
+                                                       size_t total, int logN, int limbs, long tiles_per_channel,
+                                                       ModC t, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n_ct][2][limbs][N]
+  if (idx >= total) return;
+  const size_t poly = idx >> logN;
+  const int l = (int)(poly % limbs);
+  const long c = (long)(poly / (2 * limbs)) / tiles_per_channel;
+  const int64_t s = (int64_t)scales[c];
+  const u64 mag = s < 0 ? 0 - (u64)s : (u64)s;
+  const DevMod &q = mods[l];
+  u64 scalar = reduce64(barrett128(0, mag, t.q, t.barrett_hi, t.barrett_lo), q);
+  if (s < 0 && scalar) scalar = q.q - scalar;
+  cts[idx] = mul_mod(cts[idx], scalar, q);
+}
+
+// keep[(hb, wb)][i] = i < vh*vw: the "used" coefficients of bn_direct :666-681
+__global__ __launch_bounds__(256) void bn_keep_kernel(uint8_t *__restrict__ keep, size_t total, int logN, BnTiles g) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long tile = (long)(idx >> logN), i = (long)(idx & ((size_t(1) << logN) - 1));
+  const long vh = min(g.sh, g.H - tile / g.dW * g.sh), vw = min(g.sw, g.W - tile % g.dW * g.sw);
+  keep[idx] = i < vh * vw;
+}
+
+// decryptToTensor :769-781: valid entries of a tile are read from consecutive coefficients
+__global__ __launch_bounds__(256) void bn_tensor_gather_kernel(const u64 *__restrict__ pts, u64 *__restrict__ out,
+                                                               size_t total, int logN, BnTiles g) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [C][H][W]
+  if (idx >= total) return;
+  const long ww = (long)(idx % g.W), hh = (long)(idx / g.W % g.H), c = (long)(idx / (g.W * g.H));
+  const long hb = hh / g.sh, wb = ww / g.sw, vw = min(g.sw, g.W - wb * g.sw);
+  const size_t cid = (size_t)((c * g.dH + hb) * g.dW + wb);
+  out[idx] = pts[(cid << logN) + (hh % g.sh) * vw + ww % g.sw];
+}
+}  // namespace mmh
+
+static int bn_tiles(const mmh_ctx *ctx, const mmh_bn_tensor_meta *m, BnTiles *g) {
+  MMH_REQUIRE(ctx && m, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(m->c > 0 && m->h > 0 && m->w > 0, MMH_ERR_CONFIG);
+  long n = (long)std::sqrt((double)ctx->N);  // getSplitBN :63
+  while (n * n > (long)ctx->N) --n;
+  while ((n + 1) * (n + 1) <= (long)ctx->N) ++n;
+  g->C = m->c, g->H = m->h, g->W = m->w;
+  g->sh = std::min(n, g->H), g->sw = std::min(n, g->W);
+  g->dH = (g->H + g->sh - 1) / g->sh, g->dW = (g->W + g->sw - 1) / g->sw;
+  g->n_ct = (size_t)(g->C * g->dH * g->dW);
+  return MMH_OK;
+}
+
+extern "C" int mmh_bn_tensor_count(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, size_t *n_cts,
+                                   int64_t split[3]) {
+  BnTiles g;
+  CHECK_RC(bn_tiles(ctx, meta, &g));
+  if (n_cts) *n_cts = g.n_ct;
+  if (split) split[0] = 1, split[1] = g.sh, split[2] = g.sw;
+  return MMH_OK;
+}
+
+extern "C" int mmh_bn_encode_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_tensor,
+                                    uint64_t *d_pts, void *stream) {
+  BnTiles g;
+  CHECK_RC(bn_tiles(ctx, meta, &g));
+  MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
+  MMH_REQUIRE(d_tensor && d_pts, MMH_ERR_NULL_POINTER);
+  const size_t total = g.n_ct << ctx->logN;
+  hipLaunchKernelGGL(bn_tensor_encode_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, d_tensor, d_pts,
+                     total, ctx->logN, g, ctx->bfv.t);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_bn_encrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_sk_ntt,
+                                     const uint64_t *d_tensor, const uint64_t *d_a, const int64_t *d_e,
+                                     uint64_t *d_cts, void *stream) {
+  BnTiles g;
+  CHECK_RC(bn_tiles(ctx, meta, &g));
+  MMH_REQUIRE(d_sk_ntt && d_tensor && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (g.n_ct << ctx->logN) * 8, s));
+  int rc = mmh_bn_encode_tensor(ctx, meta, d_tensor, (u64 *)pts, stream);
+  if (!rc) rc = mmh_encrypt_symmetric(ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, g.n_ct, d_cts, stream);
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}
+
+extern "C" int mmh_bn_direct_server(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_in_cts,
+                                    const uint64_t *d_share_pts, const uint64_t *d_scales,
+                                    const uint64_t *d_pk_ntt, const int64_t *d_u, const int64_t *d_e0,
+                                    const int64_t *d_e1, const uint64_t *d_share1, uint64_t *d_out_cts,
+                                    void *stream) {
+  BnTiles g;
+  CHECK_RC(bn_tiles(ctx, meta, &g));
+  MMH_REQUIRE(d_in_cts && d_scales && d_pk_ntt && d_u && d_e0 && d_e1 && d_share1 && d_out_cts, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!meta->is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = ctx->N, n = g.n_ct, S = (size_t)(g.dH * g.dW);
+  void *acc = nullptr, *zero = nullptr, *zero_low = nullptr, *rnd = nullptr, *keep = nullptr;
+  int rc = MMH_OK;
+  auto grab = [&](void **b, size_t bytes) {
+    if (!rc && hipMallocAsync(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  };
+  grab(&acc, n * 4 * N * 8);
+  grab(&zero, n * 4 * N * 8);
+  grab(&zero_low, n * 2 * N * 8);
+  grab(&rnd, n * N * 8);
+  grab(&keep, S * N);
+  // step 1 (:598-610): reconstruct the encrypted tensor
+  if (!rc && meta->is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, n, 0, (u64 *)acc, stream);
+  if (!rc && !meta->is_shared_input &&
+      hipMemcpyAsync(acc, d_in_cts, n * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    rc = MMH_ERR_INTERNAL;
+  // step 2 (:613-645): channel-wise scalar
+  if (!rc) {
+    const size_t total = n * 4 * N;
+    hipLaunchKernelGGL(bn_scale_kernel, dim3(nblk(total)), dim3(256), 0, s, (u64 *)acc, d_scales, total, ctx->logN, 2,
+                       g.dH * g.dW, ctx->bfv.t, ctx->d_mods);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  // step 3 (:648-687): mod-switch, minus Delta*encode(share1), plus a public-key encryption of zero
+  // (Encryptor::encrypt_zero at the last level = encrypt at the level above, then divide_and_round_q_last)
+  if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, n, d_out_cts, stream);
+  if (!rc) rc = mmh_bn_encode_tensor(ctx, meta, d_share1, (u64 *)rnd, stream);
+  if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)rnd, n, 1, d_out_cts, stream);
+  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 0, d_pk_ntt, d_u, d_e0, d_e1, n, (u64 *)zero, stream);
+  if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)zero, n, (u64 *)zero_low, stream);
+  if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero_low, n, stream);
+  if (!rc) {
+    hipLaunchKernelGGL(bn_keep_kernel, dim3(nblk(S * N)), dim3(256), 0, s, (uint8_t *)keep, S * N, ctx->logN, g);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, n, (const uint8_t *)keep, S, stream);
+  for (void *b : {acc, zero, zero_low, rnd, keep})
+    if (b) (void)hipFreeAsync(b, s);
+  return rc;
+}
+
+extern "C" int mmh_bn_decrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_sk_ntt,
+                                     const uint64_t *d_cts, uint64_t *d_out, void *stream) {
+  BnTiles g;
+  CHECK_RC(bn_tiles(ctx, meta, &g));
+  MMH_REQUIRE(d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(hipMallocAsync(&pts, (g.n_ct << ctx->logN) * 8, s));
+  int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, g.n_ct, (u64 *)pts, stream);
+  if (!rc) {
+    const size_t total = (size_t)(g.C * g.H * g.W);
+    hipLaunchKernelGGL(bn_tensor_gather_kernel, dim3(nblk(total)), dim3(256), 0, s, (const u64 *)pts, d_out, total,
+                       ctx->logN, g);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  (void)hipFreeAsync(pts, s);
+  return rc;
+}

@@ -336,6 +336,52 @@ void CheetahLinear::bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64
   }
 }
 
+// cheetah-api.cpp:652-706
+void CheetahLinear::bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor<uint64_t> &scale_vector,
+                              const BNMeta &meta, Tensor<uint64_t> &out_tensor) const {
+  if (meta.is_shared_input && !input_tensor.shape().IsSameSize(meta.ishape))
+    throw std::runtime_error("bn_direct input_vector shape mismatch");
+  if (meta.ishape.dims() != 3) throw std::runtime_error("bn_direct encryptVector [" + CodeMessage(Code::ERR_CONFIG) + "]");
+  const Impl &I = *impl_;
+  const size_t N = Impl::N, L = Impl::L;
+  mmh_bn_tensor_meta m{meta.ishape.channels(), meta.ishape.height(), meta.ishape.width(), meta.is_shared_input};
+  size_t n_ct = 0;
+  must(mmh_bn_tensor_count(I.ring.ctx, &m, &n_ct, nullptr), "bn_direct getSplitBN");
+  const size_t words = (size_t)meta.ishape.num_elements();
+  if (!out_tensor.shape().IsSameSize(meta.ishape)) out_tensor.Reshape(meta.ishape);
+  if (party_ == kBob) {
+    if (!input_tensor.shape().IsSameSize(meta.ishape))
+      throw std::runtime_error("bn_direct encryptVector [" + CodeMessage(Code::ERR_CONFIG) + "]");  // hom_bn_ss.cc:527
+    Dev x(words), a = I.uniform(I.ring.ctx, 0, n_ct), e = I.noise(n_ct), cts(n_ct * 2 * L * N);
+    x.upload(input_tensor.data(), words);
+    must(mmh_bn_encrypt_tensor(I.ring.ctx, &m, I.ring.sk.p, x.p, a.p, (const int64_t *)e.p, cts.p, nullptr),
+         "bn_direct encryptVector");
+    I.send_cts(cts, n_ct, 2 * L * N);
+    Dev res = I.recv_cts(n_ct, 2 * N), out(words);
+    must(mmh_bn_decrypt_tensor(I.ring.ctx, &m, I.ring.sk_last.p, res.p, out.p, nullptr), "bn_direct decryptToTensor");
+    out.download(out_tensor.data(), words);
+  } else {
+    if (scale_vector.dims() != 1 || scale_vector.length() != input_tensor.channels())
+      throw std::runtime_error("bn_direct scale_vector shape mismatch");
+    Dev scales((size_t)scale_vector.length()), in_pts;
+    scales.upload(scale_vector.data(), (size_t)scale_vector.length());
+    if (meta.is_shared_input) {
+      Dev x(words);
+      x.upload(input_tensor.data(), words);
+      in_pts.alloc(n_ct * N);
+      must(mmh_bn_encode_tensor(I.ring.ctx, &m, x.p, in_pts.p, nullptr), "bn_direct encodeVector");
+    }
+    Dev cts = I.recv_cts(n_ct, 2 * L * N);
+    Dev u = I.ternary(n_ct), e0 = I.noise(n_ct), e1 = I.noise(n_ct), share1 = I.words(words), out_cts(n_ct * 2 * N);
+    must(mmh_bn_direct_server(I.ring.ctx, &m, cts.p, in_pts.p, scales.p, I.ring.pk.p, (const int64_t *)u.p,
+                              (const int64_t *)e0.p, (const int64_t *)e1.p, share1.p, out_cts.p, nullptr),
+         "bn_direct failed");
+    share1.download(out_tensor.data(), words);  // hom_bn_ss.cc:712-723: the random tensor, reduced mod base_mod
+    for (size_t i = 0; i < words; ++i) out_tensor.data()[i] &= base_mod_ - 1;
+    I.send_cts(out_cts, n_ct, 2 * N);
+  }
+}
+
 void CheetahLinear::BOLE(const Tensor<uint64_t> &x, const Tensor<uint64_t> &y, const BNMeta &meta,
                          Tensor<uint64_t> &out_vector) const {
   if (!x.shape().IsSameSize(meta.vec_shape) || !y.shape().IsSameSize(meta.vec_shape))

@@ -70,6 +70,11 @@ SIGNATURES = {
     "mmh_conv_encode_filters": [_vp, _vp, _vp, _vp],
     "mmh_conv_encrypt_image": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_bn_tensor_count": [_vp, _vp, _vp, _vp],
+    "mmh_bn_encode_tensor": [_vp, _vp, _vp, _vp, _vp],
+    "mmh_bn_encrypt_tensor": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_bn_direct_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_bn_decrypt_tensor": [_vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],

@@ -223,6 +223,26 @@ int main(int argc, char **argv) {
     EXPECT(fok, "fc: |err| <= 1");
     std::printf("INFO bytes sent: alice %llu bob %llu\n", (unsigned long long)A2.linear->io_counter(),
                 (unsigned long long)B2.linear->io_counter());
+    // ---- bn_direct: the BatchNorm() wrapper's channel scaling (library_fixed_uniform_cheetah.cpp:465)
+    {
+      const int bc = 5, bh = full ? 56 : 9, bw_ = full ? 56 : 11;
+      CheetahLinear::BNMeta bm{TensorShape({bc, bh, bw_}), TensorShape({bc * bh * bw_}), 1ULL << l, true};
+      Tensor<u64> bs[2] = {Tensor<u64>(bm.ishape), Tensor<u64>(bm.ishape)}, bo[2], sc(TensorShape({bc}));
+      std::vector<int64_t> bx(bc * bh * bw_), bsc(bc);
+      for (size_t i = 0; i < bx.size(); ++i) {
+        bx[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+        bs[0].data()[i] = rng() & m37, bs[1].data()[i] = ((u64)bx[i] - bs[0].data()[i]) & m37;
+      }
+      for (int c = 0; c < bc; ++c) {
+        bsc[c] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+        sc.data()[c] = (u64)bsc[c];  // bn_direct reads the scale as int64 (hom_bn_ss.cc:615)
+      }
+      both(A2, B2, [&](Party &p) { p.linear->bn_direct(bs[p.id - 1], sc, bm, bo[p.id - 1]); });
+      bool bok = bo[0].shape().IsSameSize(bm.ishape) && bo[1].shape().IsSameSize(bm.ishape);
+      for (size_t i = 0; i < bx.size() && bok; ++i)
+        bok &= to_signed(bo[0].data()[i] + bo[1].data()[i], l) == bx[i] * bsc[i / (bh * bw_)];
+      EXPECT(bok, "bn_direct: exact channel-wise scaling");
+    }
     // error behaviour: shape mismatch throws invalid_argument like cheetah-api.cpp:381-383
     bool threw = false;
     try {

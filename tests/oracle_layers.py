@@ -354,3 +354,89 @@ class BnOracle:
             lo, hi = k * self.sub, min((k + 1) * self.sub, self.n)
             out[lo:hi] = slots[:hi - lo]
         return out
+
+
+class BnDirectOracle:
+    """HomBNSS direct path (hom_bn_ss.cc:471-790) on an oracle context with t = 2^k, followed
+    line by line, including the dense indexing of the re-sharing / decrypt side."""
+
+    def __init__(self, o, ishape, shared=True):
+        import math
+        self.o, self.lib, self.ishape, self.shared = o, load(), tuple(ishape), shared
+        n = math.isqrt(o.N)                                             # getSplitBN :63
+        C_, H, W = ishape
+        self.sh, self.sw = min(n, H), min(n, W)
+        self.dH, self.dW = -(-H // self.sh), -(-W // self.sw)
+        self.n_ct = C_ * self.dH * self.dW
+
+    def _tile(self, cid):
+        c, hb, wb = cid // (self.dH * self.dW), (cid // self.dW) % self.dH, cid % self.dW
+        return c, hb * self.sh, wb * self.sw
+
+    def encode(self, tensor):                                           # :471-520
+        N, t = self.o.N, self.o.t
+        C_, H, W = self.ishape
+        out = np.zeros((self.n_ct, N), np.uint64)
+        for cid in range(self.n_ct):
+            c, h0, w0 = self._tile(cid)
+            tile = np.zeros((self.sh, self.sw), np.uint64)              # SlicedPaddedTensor pads with zeros
+            vh, vw = min(self.sh, H - h0), min(self.sw, W - w0)
+            tile[:vh, :vw] = tensor[c, h0:h0 + vh, w0:w0 + vw]
+            out[cid, :self.sh * self.sw] = tile.ravel() % np.uint64(t)  # vec2PolyBFV :465
+        return out
+
+    def encrypt(self, sk, tensor, a, e):                                # :522-576
+        pts = self.encode(tensor)
+        cts = np.zeros((self.n_ct, 2, self.o.L, self.o.N), np.uint64)
+        for k in range(self.n_ct):
+            self.lib.mmo_encrypt_symmetric(self.o.p, 0, A(sk), A(a[k]), A(e[k]), A(pts[k]), self.o.N, A(cts[k]))
+        return cts
+
+    def server(self, cts, share_pts, scales, pk, u, e0, e1, share1):    # :578-738
+        o, lib, N, t = self.o, self.lib, self.o.N, self.o.t
+        C_, H, W = self.ishape
+        acc = cts.copy()
+        if self.shared:                                                 # :598-604
+            for k in range(self.n_ct):
+                lib.mmo_add_plain(o.p, 0, A(acc[k]), A(share_pts[k]), N)
+        for c in range(C_):                                             # :613-645
+            s = int(np.int64(scales[c]))
+            v = abs(s) % t
+            for cid in range(c * self.dH * self.dW, (c + 1) * self.dH * self.dW):
+                for l, q in enumerate(o.q):
+                    scalar = v % q
+                    if s < 0 and scalar:
+                        scalar = q - scalar
+                    vec = np.full(N, scalar, np.uint64)
+                    for comp in range(2):
+                        lib.mmo_dyadic_mul(A(acc[cid, comp, l]), A(vec), A(acc[cid, comp, l]), N, q)
+        rnd = self.encode(share1)                                       # :725
+        out = np.zeros((self.n_ct, 2, 1, N), np.uint64)
+        m0, m1 = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        lib.mmo_truncate_masks(o.p, A(m0), A(m1))
+        zero, zero_low = np.zeros((2, o.L, N), np.uint64), np.zeros((2, 1, N), np.uint64)
+        for cid in range(self.n_ct):                                    # :648-687
+            lib.mmo_mod_switch_to_last(o.p, A(acc[cid]), A(out[cid]), 2)
+            lib.mmo_sub_plain(o.p, 1, A(out[cid]), A(rnd[cid]), N)
+            # Encryptor::encrypt_zero(last_parms_id): pk encryption one level up, then divide_and_round_q_last
+            lib.mmo_encrypt_zero_asymmetric(o.p, 0, A(pk), A(u[cid]), A(e0[cid]), A(e1[cid]), A(zero))
+            lib.mmo_mod_switch_to_last(o.p, A(zero), A(zero_low), 2)
+            lib.mmo_ct_add(o.p, 1, A(out[cid]), A(zero_low), 2)
+            _, h0, w0 = self._tile(cid)
+            used = min(self.sh, H - h0) * min(self.sw, W - w0)          # indices 0 .. used-1, :666-678
+            out[cid, 0, 0, used:] = 0                                   # remove_unused_coeffs: c0 only
+            out[cid, 0] &= m0[0]
+            out[cid, 1] &= m1[0]
+        return out
+
+    def decrypt(self, sk1, cts):                                        # :740-790
+        N = self.o.N
+        C_, H, W = self.ishape
+        out = np.zeros(self.ishape, np.uint64)
+        pt = np.zeros(N, np.uint64)
+        for cid in range(self.n_ct):
+            self.lib.mmo_decrypt(self.o.p, 1, A(sk1), A(cts[cid]), A(pt))
+            c, h0, w0 = self._tile(cid)
+            vh, vw = min(self.sh, H - h0), min(self.sw, W - w0)
+            out[c, h0:h0 + vh, w0:w0 + vw] = pt[:vh * vw].reshape(vh, vw)
+        return out

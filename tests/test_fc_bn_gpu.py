@@ -164,3 +164,63 @@ def test_bole_full_size_identity(mm):
     out_b = bole_cross_term(dec, x0, y0, P32)
     out_a = bole_cross_term(share, x1, y1, P32)
     assert torch.equal((out_a + out_b) % P32, (x * y) % P32)
+
+
+@pytest.mark.parametrize("ishape,shared", [((3, 10, 12), True), ((2, 64, 64), False), ((2, 70, 64), True),
+                                           ((1, 10, 70), True), ((5, 1, 1), True)])
+def test_bn_direct_bit_exact(mm, ishape, shared):
+    """HomBNSS direct path (hom_bn_ss.cc:471-790) against the oracle at every step; (1,10,70) has a
+    tile that is ragged in w, where the reference's encoder and its dense decrypt indexing disagree --
+    the bits must still match the restatement."""
+    from openmm_amd.hom_bn_ss import HomBNSS, TensorMeta
+    from tests.oracle_layers import BnDirectOracle
+    T = 1 << 37
+    o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
+    bn = BnDirectOracle(o, ishape, shared)
+    meta = TensorMeta(ishape, T, shared)
+    sk, pk = keypair(o)
+    client, server = HomBNSS(), HomBNSS()
+    client.setUp_Base(T, g, sk_ntt=dev(sk))
+    server.setUp_Base(T, g, pk_ntt=dev(pk))
+    x0 = splitmix64(SEED + 1, int(np.prod(ishape))).reshape(ishape)      # unreduced: encode takes mod t
+    x1 = uniform_mod(SEED + 2, ishape, T)
+    scales = ((splitmix64(SEED + 3, ishape[0]) % np.uint64(8191)).astype(np.int64) - 4095).view(np.uint64)
+    a, e = rns_uniform(o, SEED + 10, bn.n_ct, 2), noise(SEED + 11, (bn.n_ct, N))
+    ref_cts = bn.encrypt(sk, x0, a, e)
+    got_cts = client.encryptTensor(dev(x0), meta, (dev(a), dev(e)))
+    assert np.array_equal(host(got_cts), ref_cts)
+    ref_pts = got_pts = None
+    if shared:
+        ref_pts, got_pts = bn.encode(x1), server.encodeTensor(dev(x1), meta)
+        assert np.array_equal(host(got_pts), ref_pts)
+    u, e0, e1 = ternary(SEED + 20, (bn.n_ct, N)), noise(SEED + 21, (bn.n_ct, N)), noise(SEED + 22, (bn.n_ct, N))
+    share1 = uniform_mod(SEED + 30, ishape, T)
+    ref_out = bn.server(ref_cts, ref_pts, scales, pk, u, e0, e1, share1)
+    got_out, got_share = server.bn_direct(got_cts, got_pts, dev(scales), meta, (dev(u), dev(e0), dev(e1), dev(share1)))
+    assert np.array_equal(host(got_out), ref_out)
+    assert np.array_equal(host(got_cts), ref_cts)  # inputs are not destroyed
+    got_dec = host(client.decryptToTensor(got_out, meta))
+    assert np.array_equal(got_dec, bn.decrypt(np.ascontiguousarray(sk[:1]), ref_out))
+    if ishape[2] <= 64 or ishape[2] % 64 == 0:      # no tile ragged in w: the protocol identity holds exactly
+        s = scales.view(np.int64).astype(object)[:, None, None]
+        xs = (x0.astype(object) + (x1.astype(object) if shared else 0)) * s
+        assert np.array_equal((got_dec.astype(object) + host(got_share).astype(object)) % T, xs % T)
+
+
+def test_bn_direct_errors(mm):
+    import torch
+    from openmm_amd.hom_bn_ss import HomBNSS, TensorMeta
+    T = 1 << 37
+    g = mm.Context(N, (60, 49), T)
+    h = HomBNSS()
+    with pytest.raises(mm.MMHError) as ei:   # setUp_Base: plain modulus mismatch -> ERR_INVALID_ARG
+        h.setUp_Base(1 << 36, g)
+    assert ei.value.code == 7
+    h.setUp_Base(T, g)
+    meta = TensorMeta((2, 4, 4), T, True)
+    with pytest.raises(mm.MMHError) as ei:   # shape mismatch -> ERR_CONFIG (hom_bn_ss.cc:475)
+        h.encodeTensor(torch.zeros((2, 4, 5), dtype=torch.int64, device="cuda"), meta)
+    assert ei.value.code == 1
+    with pytest.raises(mm.MMHError) as ei:   # no public key -> ERR_CONFIG
+        h.bn_direct(None, None, None, meta, None)
+    assert ei.value.code == 1

@@ -57,3 +57,25 @@ def test_bole_and_bn_flow_reconstruct(n):
     dec = bn.decrypt(sk1, out_cts)
     want = ((x0.astype(object) + x1.astype(object)) * scale.astype(object)) % P32
     assert np.array_equal((dec.astype(object) + share.astype(object)) % P32, want)
+
+
+@pytest.mark.parametrize("ishape,shared", [((3, 10, 12), True), ((2, 64, 64), False), ((2, 70, 64), True)])
+def test_bn_direct_flow_reconstructs(ishape, shared):
+    """BatchNorm() wrapper (library_fixed_uniform_cheetah.cpp:465): out0 + out1 = x * scale mod 2^k,
+    exact because the re-sharing is a sub_plain.  Tiles that are not ragged in w only: for those the
+    reference's dense used-index / decrypt layout matches its encoder (hom_bn_ss.cc:666-678)."""
+    from tests.oracle_layers import BnDirectOracle
+    o = OracleCtx(N, (60, 49), T)
+    bn = BnDirectOracle(o, ishape, shared)
+    sk, pk = keypair(o)
+    x0 = uniform_mod(SEED + 1, ishape, T)
+    x1 = uniform_mod(SEED + 2, ishape, T) if shared else np.zeros(ishape, np.uint64)
+    scales = ((splitmix64(SEED + 3, ishape[0]) % np.uint64(8191)).astype(np.int64) - 4095).view(np.uint64)  # both signs
+    cts = bn.encrypt(sk, x0, rns_uniform(o, SEED + 10, bn.n_ct, 2), noise(SEED + 11, (bn.n_ct, N)))
+    u, e0, e1 = ternary(SEED + 20, (bn.n_ct, N)), noise(SEED + 21, (bn.n_ct, N)), noise(SEED + 22, (bn.n_ct, N))
+    share1 = uniform_mod(SEED + 30, ishape, T)
+    out = bn.server(cts, bn.encode(x1) if shared else None, scales, pk, u, e0, e1, share1)
+    dec = bn.decrypt(np.ascontiguousarray(sk[:1]), out)
+    s = scales.view(np.int64).astype(object)[:, None, None]
+    want = ((x0.astype(object) + x1.astype(object)) * s) % T
+    assert np.array_equal((dec.astype(object) + share1.astype(object)) % T, want)
