@@ -166,6 +166,13 @@ int mmh_sub_rns_poly(const mmh_ctx *ctx, int lv, uint64_t *d_cts, const uint64_t
  * walks ct.data(0) only, so c1 keeps all its coefficients).
  * Masks: mmh_truncate_masks. */
 int mmh_truncate_masks(const mmh_ctx *ctx, uint64_t *mask0, uint64_t *mask1);
+/* flood_ciphertext's noise step of the USE_APPROX_RESHARE=0 build (hom_conv2d_ss.cc:358-380 with
+ * set_poly_coeffs_uniform :142-177): first-level cts [n][2][L][N], c0[l] += (random & bitmask) mod q_l,
+ * bitlen = min(64, bits(Q) - bits(t) - 1), bitmask = (1 << (bitlen % 64)) - 1 exactly as written at
+ * :154 (so 0 when bitlen = 64).  d_random [n][N] raw words. */
+int mmh_flood_add(const mmh_ctx *ctx, uint64_t *d_cts, const uint64_t *d_random, size_t n, void *stream);
+/* modulo_poly_coeffs with the plain modulus (hom_conv2d_ss.cc:257-265, hom_bn_ss.cc:715-723) */
+int mmh_reduce_mod_t(const mmh_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t count, void *stream);
 int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t n, const uint8_t *d_keep,
                           size_t keep_period, void *stream);
 
@@ -240,6 +247,15 @@ int mmh_conv_server(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const u
                     const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                     const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
                     void *stream);
+/* conv2DSS as compiled with USE_APPROX_RESHARE=0 (CMakeLists.txt:31-35; scripts/build.sh ships =ON):
+ * flood_ciphertext first adds (d_flood & bitmask) mod q_l to c0 (hom_conv2d_ss.cc:358-380, d_flood
+ * [n_out][N] raw 64-bit words), the zero encryption keeps e0 (:327), and sample_random_mask :225-272
+ * draws the mask mod t (d_mask [n_out][N] raw words, reduced here), subtracts it with sub_plain and
+ * returns it as the share.  Everything else as mmh_conv_server. */
+int mmh_conv_server_exact(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                          const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const uint64_t *d_flood,
+                          const int64_t *d_u, const int64_t *d_e0, const int64_t *d_e1, const uint64_t *d_mask,
+                          uint64_t *d_out_cts, uint64_t *d_out_share, void *stream);
 /* The server half of CheetahLinear::conv2d in one call (cheetah-api.cpp:417-445: encodeFilters
  * followed by conv2DSS): as mmh_conv_server but from the raw filters d_filters [M][C][fh][fw].
  * Each filter polynomial is encoded, lifted and transformed on chip, so the sparse plaintexts of
@@ -280,6 +296,11 @@ int mmh_fc_server(const mmh_fc_plan *plan, const uint64_t *d_in_cts, const uint6
                   const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                   const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
                   void *stream);
+/* matVecMul as compiled with USE_APPROX_RESHARE=0; extra arguments as mmh_conv_server_exact */
+int mmh_fc_server_exact(const mmh_fc_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                        const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const uint64_t *d_flood,
+                        const int64_t *d_u, const int64_t *d_e0, const int64_t *d_e1, const uint64_t *d_mask,
+                        uint64_t *d_out_cts, uint64_t *d_out_share, void *stream);
 /* HomFCSS::decryptToVector (hom_fc_ss.cc:572-602) */
 int mmh_fc_decrypt(const mmh_fc_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_cts, uint64_t *d_out,
                    void *stream);

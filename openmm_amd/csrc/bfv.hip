@@ -138,6 +138,27 @@ __global__ __launch_bounds__(256) void sub_c0_kernel(u64 *__restrict__ cts, cons
   *d = sub_mod(*d, r[idx], mods[l].q);
 }
 
+// flood_ciphertext, exact build (hom_conv2d_ss.cc:358-380): c0[l] += (random & bitmask) mod q_l
+__global__ __launch_bounds__(256) void flood_add_kernel(u64 *__restrict__ cts, const u64 *__restrict__ random,
+                                                        size_t total, int logN, int limbs, u64 bitmask,
+                                                        const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const u64 r = random[idx] & bitmask;
+  for (int l = 0; l < limbs; ++l) {
+    u64 *d = cts + (((k * 2) * limbs + l) << logN) + i;
+    *d = add_mod(*d, reduce64(r, mods[l]), mods[l].q);
+  }
+}
+
+// v mod t element-wise
+__global__ __launch_bounds__(256) void reduce_t_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t total,
+                                                       ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) out[idx] = reduce128(0, in[idx], t);
+}
+
 __global__ __launch_bounds__(256) void mod_switch_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
                                                          size_t total, int logN, u64 inv_qlast,
                                                          const DevMod *__restrict__ mods) {
@@ -521,6 +542,35 @@ extern "C" int mmh_sub_rns_poly(const mmh_ctx *ctx, int lv, uint64_t *d_cts, con
   const int limbs = limbs_of(ctx, lv);
   const size_t total = n * limbs * ctx->N;
   LAUNCH(sub_c0_kernel, total, (hipStream_t)stream, d_cts, d_r, total, ctx->logN, limbs, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_flood_add(const mmh_ctx *ctx, uint64_t *d_cts, const uint64_t *d_random, size_t n, void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts && d_random, MMH_ERR_NULL_POINTER);
+  // noise_len = total_coeff_modulus_bit_count - bit_count(t) - 1, capped at 64 (:361-368); the mask
+  // is (1 << (bitlen % 64)) - 1 as written at :154, which is 0 for bitlen = 64
+  unsigned __int128 Q = 1;
+  MMH_REQUIRE(ctx->L <= 2, MMH_ERR_CONFIG);
+  for (size_t l = 0; l < ctx->L; ++l) Q *= ctx->h_mods[l].q;
+  int q_bits = 0, t_bits = 0;
+  while (Q) ++q_bits, Q >>= 1;
+  for (u64 t = ctx->t; t; t >>= 1) ++t_bits;
+  const int bitlen = std::min(64, q_bits - t_bits - 1);
+  MMH_REQUIRE(bitlen >= 0, MMH_ERR_CONFIG);
+  const u64 bitmask = (1ULL << (bitlen % 64)) - 1;
+  LAUNCH(flood_add_kernel, n * ctx->N, (hipStream_t)stream, d_cts, d_random, n * ctx->N, ctx->logN, (int)ctx->L,
+         bitmask, ctx->d_mods);
+  return MMH_OK;
+}
+
+extern "C" int mmh_reduce_mod_t(const mmh_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t count,
+                                void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  if (count == 0) return MMH_OK;
+  MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
+  LAUNCH(reduce_t_kernel, count, (hipStream_t)stream, d_in, d_out, count, ctx->bfv.t);
   return MMH_OK;
 }
 

@@ -313,7 +313,10 @@ extern "C" int mmh_conv_encrypt_image(const mmh_conv_plan *p, const uint64_t *d_
 static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
                             const uint64_t *d_filter_pts, const uint64_t *d_filters_raw,
                             const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
-                            const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream) {
+                            const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream,
+                            const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr) {
+  const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
+  MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw) && d_pk_ntt_last && d_u && d_e1 && d_mask &&
                   d_out_cts && d_out_share,
               MMH_ERR_NULL_POINTER);
@@ -322,10 +325,10 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
-  void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr;
+  void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr, *mask_t = nullptr;
   int rc = MMH_OK;
   auto cleanup = [&]() {
-    for (void *b : {image, acc, zero, f_ntt})
+    for (void *b : {image, acc, zero, f_ntt, mask_t})
       if (b) (void)hipFreeAsync(b, s);
   };
   auto grab = [&](void **b, size_t bytes) {
@@ -350,15 +353,27 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
   if (!rc) rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, (const u64 *)f_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
   if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
-  // addRandomMask :761-788: flood_ciphertext (mod-switch + pk-encryption of zero without e0),
+  // addRandomMask :761-788: flood_ciphertext (exact build: uniform noise on c0 first; mod-switch;
+  // pk-encryption of zero, without e0 in the approximate build),
+  if (!rc && exact) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
   if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
-  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, nullptr, d_e1, p->n_out, (u64 *)zero, stream);
+  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
   if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
-  // ... sample_random_mask (approximate re-sharing) + sub_poly_inplace, share scattered into the tensor
-  if (!rc) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
-  if (!rc)
+  // ... sample_random_mask + sub_poly_inplace, share scattered into the tensor.  Approximate build: the
+  // mask is an RNS polynomial and the share its scale-and-round; exact build: the mask is a plaintext
+  // mod t, subtracted by sub_plain, and the share is the mask itself (:225-272)
+  if (!rc && !exact) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
+  if (!rc && !exact)
     rc = launch_share_from_mask(ctx, d_mask, d_out_share, M, p->n_targets, S, (size_t)(p->out_h * p->out_w),
                                 p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  if (exact) {
+    grab(&mask_t, p->n_out * N * 8);
+    if (!rc) rc = mmh_reduce_mod_t(ctx, d_mask, (u64 *)mask_t, p->n_out * N, stream);
+    if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)mask_t, p->n_out, 1, d_out_cts, stream);
+    if (!rc)
+      rc = launch_gather_targets(ctx, (const u64 *)mask_t, d_out_share, M, p->n_targets, S,
+                                 (size_t)(p->out_h * p->out_w), p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  }
   // truncate_for_decryption :698-703 and removeUnusedCoeffs :800-851 in one pass
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, S, stream);
   cleanup();
@@ -372,6 +387,16 @@ extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts,
   MMH_REQUIRE(d_filter_pts, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, d_filter_pts, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask,
                           d_out_cts, d_out_share, stream);
+}
+
+extern "C" int mmh_conv_server_exact(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                                     const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last,
+                                     const uint64_t *d_flood, const int64_t *d_u, const int64_t *d_e0,
+                                     const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                                     uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(d_filter_pts && d_flood && d_e0, MMH_ERR_NULL_POINTER);
+  return conv_server_impl(p, d_in_cts, d_share_pts, d_filter_pts, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask,
+                          d_out_cts, d_out_share, stream, d_flood, d_e0);
 }
 
 extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d_in_cts,

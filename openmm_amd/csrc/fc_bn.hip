@@ -196,10 +196,12 @@ extern "C" int mmh_fc_encrypt_input(const mmh_fc_plan *p, const uint64_t *d_sk_n
   return rc;
 }
 
-extern "C" int mmh_fc_server(const mmh_fc_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
-                             const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
-                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
-                             uint64_t *d_out_share, void *stream) {
+static int fc_server_impl(const mmh_fc_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                          const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                          const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
+                          void *stream, const uint64_t *d_flood, const int64_t *d_e0) {
+  const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
+  MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(p && d_in_cts && d_weight_pts && d_pk_ntt_last && d_u && d_e1 && d_mask && d_out_cts && d_out_share,
               MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);  // matVecMul :424-426
@@ -207,7 +209,7 @@ extern "C" int mmh_fc_server(const mmh_fc_plan *p, const uint64_t *d_in_cts, con
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N;
-  void *input = nullptr, *acc = nullptr, *zero = nullptr;
+  void *input = nullptr, *acc = nullptr, *zero = nullptr, *mask_t = nullptr;
   int rc = MMH_OK;
   const u64 *cts = d_in_cts;
   if (p->meta.is_shared_input) {  // :431-440
@@ -221,20 +223,49 @@ extern "C" int mmh_fc_server(const mmh_fc_plan *p, const uint64_t *d_in_cts, con
   if (!rc)
     rc = mmh_mul_plain_acc(ctx, 0, cts, p->n_in, d_weight_pts, p->n_out * p->n_in, p->n_out, 1, p->n_in, 1, 0,
                            p->n_in, 1, 0, (u64 *)acc, stream);
-  // addRandomMask :487-517 (the output vector is sized once, not per worker as the reference does)
+  // addRandomMask :487-517 (the output vector is sized once, not per worker as the reference does);
+  // the two re-sharing builds differ as in HomConv2DSS (hom_conv2d_ss.cc:179-273, :323-328, :358-380)
+  if (!rc && exact) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
   if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
-  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, nullptr, d_e1, p->n_out, (u64 *)zero, stream);
+  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
   if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
-  if (!rc) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
-  if (!rc)
+  if (!rc && !exact) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
+  if (!rc && !exact)
     rc = launch_share_from_mask(ctx, d_mask, d_out_share, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
                                 p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  if (exact) {
+    if (!rc && hipMallocAsync(&mask_t, p->n_out * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+    if (!rc) rc = mmh_reduce_mod_t(ctx, d_mask, (u64 *)mask_t, p->n_out * N, stream);
+    if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)mask_t, p->n_out, 1, d_out_cts, stream);
+    if (!rc)
+      rc = launch_gather_targets(ctx, (const u64 *)mask_t, d_out_share, 1, p->n_targets, p->n_out,
+                                 (size_t)p->meta.rows, p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  }
   // truncate_for_decryption :462-466 + removeUnusedCoeffs :525-561
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, p->n_out, stream);
   if (input) (void)hipFreeAsync(input, s);
   if (acc) (void)hipFreeAsync(acc, s);
   if (zero) (void)hipFreeAsync(zero, s);
+  if (mask_t) (void)hipFreeAsync(mask_t, s);
   return rc;
+}
+
+extern "C" int mmh_fc_server(const mmh_fc_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                             const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                             uint64_t *d_out_share, void *stream) {
+  return fc_server_impl(p, d_in_cts, d_share_pts, d_weight_pts, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
+                        d_out_share, stream, nullptr, nullptr);
+}
+
+extern "C" int mmh_fc_server_exact(const mmh_fc_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                                   const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last,
+                                   const uint64_t *d_flood, const int64_t *d_u, const int64_t *d_e0,
+                                   const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                                   uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(d_flood && d_e0, MMH_ERR_NULL_POINTER);
+  return fc_server_impl(p, d_in_cts, d_share_pts, d_weight_pts, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
+                        d_out_share, stream, d_flood, d_e0);
 }
 
 extern "C" int mmh_fc_decrypt(const mmh_fc_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,

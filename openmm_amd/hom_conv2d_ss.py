@@ -120,8 +120,9 @@ class HomConv2DSS:
         out._mm_nonzero = bool((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
         return out
 
-    # conv2DSS (hom_conv2d_ss.cc:621-712); rand = (u [n_out,N], e1 [n_out,N], mask [n_out,N])
-    def conv2DSS(self, img_share0, img_share1, filters, meta, rand):
+    # conv2DSS (hom_conv2d_ss.cc:621-712); rand = (u [n_out,N], e1 [n_out,N], mask [n_out,N]) for the
+    # shipped USE_APPROX_RESHARE build, (flood, u, e0, e1, mask) with exact=True for the other build
+    def conv2DSS(self, img_share0, img_share1, filters, meta, rand, exact=False):
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         p = self.plan(meta)
         self._need(filters.shape[0] == meta.n_filters, 3, "conv2DSS: #filters")
@@ -133,9 +134,17 @@ class HomConv2DSS:
         if nz is None:  # polynomials that did not come from encodeFilters: look at them
             nz = bool((filters.reshape(meta.n_filters, -1) != 0).any(dim=1).all())
         self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
-        u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)
+        if exact:
+            flood, u, e0, e1, mask = rand
+            L.check(self.ctx.lib.mmh_conv_server_exact(p.handle, L.dptr(img_share0),
+                                                       L.dptr(img_share1 if meta.is_shared_input else None),
+                                                       L.dptr(filters), L.dptr(self.pk_last), L.dptr(flood),
+                                                       L.dptr(u), L.dptr(e0), L.dptr(e1), L.dptr(mask),
+                                                       L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+            return out_cts, out_share
+        u, e1, mask = rand
         L.check(self.ctx.lib.mmh_conv_server(p.handle, L.dptr(img_share0),
                                              L.dptr(img_share1 if meta.is_shared_input else None),
                                              L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),

@@ -89,7 +89,8 @@ class HomFCSS:
         out._mm_nonzero = bool(nz.view(p.n_out, d0, p.n_in, d1).any(dim=3).any(dim=1).all())
         return out
 
-    def matVecMul(self, matrix, vec_share0, vec_share1, meta, rand):  # :394-471
+    # :394-471; rand = (u, e1, mask) or, exact=True (USE_APPROX_RESHARE=0 build), (flood, u, e0, e1, mask)
+    def matVecMul(self, matrix, vec_share0, vec_share1, meta, rand, exact=False):
         self._need(self.pk_ntt is not None, 1, "matVecMul: no public key")
         p = self.plan(meta)
         self._need(vec_share0.shape[0] == p.n_in, 7, "matVecMul: #input ciphertexts")
@@ -101,9 +102,17 @@ class HomFCSS:
         self._need(nz, 7, "matVecMul: sub-matrix with all zero is not supported")
         if meta.is_shared_input:
             self._need(vec_share1 is not None and vec_share1.shape[0] == p.n_in, 3, "matVecMul: #shares")
-        u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(meta.weight_shape[0])
+        if exact:
+            flood, u, e0, e1, mask = rand
+            L.check(self.ctx.lib.mmh_fc_server_exact(p.handle, L.dptr(vec_share0),
+                                                     L.dptr(vec_share1 if meta.is_shared_input else None),
+                                                     L.dptr(matrix), L.dptr(self.pk_last), L.dptr(flood), L.dptr(u),
+                                                     L.dptr(e0), L.dptr(e1), L.dptr(mask), L.dptr(out_cts),
+                                                     L.dptr(out_share), L._stream_ptr()))
+            return out_cts, out_share
+        u, e1, mask = rand
         L.check(self.ctx.lib.mmh_fc_server(p.handle, L.dptr(vec_share0),
                                            L.dptr(vec_share1 if meta.is_shared_input else None), L.dptr(matrix),
                                            L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),

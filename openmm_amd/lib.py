@@ -75,6 +75,10 @@ SIGNATURES = {
     "mmh_bn_encrypt_tensor": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_bn_direct_server": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_bn_decrypt_tensor": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server_exact": [_vp] * 13,
+    "mmh_fc_server_exact": [_vp] * 13,
+    "mmh_flood_add": [_vp, _vp, _vp, _sz, _vp],
+    "mmh_reduce_mod_t": [_vp, _vp, _vp, _sz, _vp],
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],

@@ -100,8 +100,8 @@ class ConvOracle:
             self.lib.mmo_encrypt_symmetric(self.o.p, 0, A(sk), A(a[k]), A(e[k]), A(pts[k]), self.o.N, A(cts[k]))
         return cts
 
-    def server(self, in_cts, share_pts, filter_pts, pk1, u, e1, mask):
-        """conv2DSS, USE_APPROX_RESHARE build"""
+    def server(self, in_cts, share_pts, filter_pts, pk1, u, e1, mask, exact=None):
+        """conv2DSS, USE_APPROX_RESHARE build; exact=(flood, e0) selects the other build"""
         o, lib, N, L = self.o, self.lib, self.o.N, self.o.L
         image = in_cts.copy()
         if self.shared:
@@ -139,6 +139,13 @@ class ConvOracle:
                 for sw in range(nsw):
                     (th, tw), tg = self.targets(self.mask_ix, sh, sw)
                     ct = low[cid]
+                    if exact is not None:
+                        r = exact_reshare(o, lib, out[cid], ct, pk1, exact[0][cid], u[cid], exact[1][cid], e1[cid],
+                                          mask[cid])
+                        share[m, hoff:hoff + th, woff:woff + tw] = r[tg.astype(np.int64)].reshape(th, tw)
+                        woff += tw
+                        cid += 1
+                        continue
                     lib.mmo_mod_switch_to_last(o.p, A(out[cid]), A(ct), 2)                 # flood :382
                     lib.mmo_encrypt_zero_asymmetric(o.p, 1, A(pk1), A(u[cid]), None, A(e1[cid]), A(zero))
                     lib.mmo_ct_add(o.p, 1, A(ct), A(zero), 2)
@@ -233,7 +240,7 @@ class FcOracle:
             self.lib.mmo_encrypt_symmetric(self.o.p, 0, A(sk), A(a[k]), A(e[k]), A(pts[k]), self.o.N, A(cts[k]))
         return cts
 
-    def server(self, in_cts, share_pts, wpts, pk1, u, e1, mask):
+    def server(self, in_cts, share_pts, wpts, pk1, u, e1, mask, exact=None):
         o, lib, N, L = self.o, self.lib, self.o.N, self.o.L
         inp = in_cts.copy()
         if self.shared:
@@ -252,6 +259,11 @@ class FcOracle:
         targets = np.arange(self.d0, dtype=np.int64) * self.d1           # :482-485
         q0 = np.uint64(o.q[0])
         for j in range(self.n_out):                                      # :494-511
+            if exact is not None:
+                r = exact_reshare(o, lib, out[j], low[j], pk1, exact[0][j], u[j], exact[1][j], e1[j], mask[j])
+                r0, r1 = j * self.d0, min((j + 1) * self.d0, self.rows)
+                share[r0:r1] = r[targets][:r1 - r0]
+                continue
             lib.mmo_mod_switch_to_last(o.p, A(out[j]), A(low[j]), 2)
             lib.mmo_encrypt_zero_asymmetric(o.p, 1, A(pk1), A(u[j]), None, A(e1[j]), A(zero))
             lib.mmo_ct_add(o.p, 1, A(low[j]), A(zero), 2)
@@ -282,6 +294,35 @@ class FcOracle:
             r0, r1 = j * self.d0, min((j + 1) * self.d0, self.rows)
             out[r0:r1] = pt[(np.arange(r1 - r0)) * self.d1]
         return out
+
+
+def flood_noise(o, flood_words):
+    """set_poly_coeffs_uniform as flood_ciphertext calls it (hom_conv2d_ss.cc:142-177, :358-368):
+    [L][N] residues of (word & bitmask), bitmask = (1 << (bitlen % 64)) - 1 as written"""
+    Q = 1
+    for q in o.q:
+        Q *= q
+    bitlen = min(64, Q.bit_length() - int(o.t).bit_length() - 1)
+    bitmask = np.uint64((1 << (bitlen % 64)) - 1)
+    r = flood_words & bitmask
+    return np.stack([r % np.uint64(q) for q in o.q])
+
+
+def exact_reshare(o, lib, acc, low, pk1, flood, u, e0, e1, mask_words):
+    """flood_ciphertext + sample_random_mask + sub_poly_inplace of the USE_APPROX_RESHARE=0 build for
+    one ciphertext; returns the mask polynomial mod t (the share is read from it at the targets)"""
+    N = o.N
+    noise = flood_noise(o, flood)
+    for l, q in enumerate(o.q):                                          # :370-379, c0 only
+        lib.mmo_add_mod(A(acc[0, l]), A(noise[l]), A(acc[0, l]), N, q)
+    lib.mmo_mod_switch_to_last(o.p, A(acc), A(low), 2)                   # :382
+    zero = np.zeros((2, 1, N), np.uint64)
+    lib.mmo_encrypt_zero_asymmetric(o.p, 1, A(pk1), A(u), A(e0), A(e1), A(zero))   # :327 keeps e0
+    lib.mmo_ct_add(o.p, 1, A(low), A(zero), 2)
+    t = int(o.t)
+    r = (mask_words & np.uint64(t - 1)) if t & (t - 1) == 0 else mask_words % np.uint64(t)   # :257-265
+    lib.mmo_sub_plain(o.p, 1, A(low), A(np.ascontiguousarray(r)), N)     # sub_poly_inplace :74-81
+    return r
 
 
 class BnOracle:

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from tests.layer_fixtures import SEED, keypair, noise, rns_uniform, signed_weights, ternary
-from tests.oracle_binding import OracleCtx, uniform_mod
+from tests.oracle_binding import OracleCtx, splitmix64, uniform_mod
 from tests.oracle_layers import ConvOracle, ideal_conv
 
 pytestmark = pytest.mark.gpu
@@ -87,6 +87,15 @@ def test_conv_layer_bit_exact(mm, ishape, fhw, M, same, stride, shared):
     one_out, one_share = server.conv2DSSFromWeights(got_cts, got_s, dev(filters), meta, (dev(u), dev(e1), dev(mask)))
     assert np.array_equal(host(one_out), ref_out)
     assert np.array_equal(host(one_share), ref_share)
+    # the USE_APPROX_RESHARE=0 build of the same call: flood noise, e0 kept, mask mod t; exact identity
+    flood, e0 = splitmix64(SEED + 60, cv.n_out * N).reshape(cv.n_out, N), noise(SEED + 61, (cv.n_out, N))
+    words = splitmix64(SEED + 62, cv.n_out * N).reshape(cv.n_out, N)
+    x_out, x_share = cv.server(ref_cts, ref_s, ref_f, np.ascontiguousarray(pk[:, :1]), u, e1, words, exact=(flood, e0))
+    y_out, y_share = server.conv2DSS(got_cts, got_s, got_f, meta, (dev(flood), dev(u), dev(e0), dev(e1), dev(words)),
+                                     exact=True)
+    assert np.array_equal(host(y_out), x_out) and np.array_equal(host(y_share), x_share)
+    y_dec = host(client.decryptToTensor(y_out, meta))
+    assert np.array_equal((y_dec.astype(object) + x_share.astype(object)) % T, ideal_conv(img, filters, same, stride, T))
     # client: decryptToTensor, then the reference's acceptance identity
     ref_dec = cv.decrypt(np.ascontiguousarray(sk[:1]), ref_out)
     got_dec = host(client.decryptToTensor(got_out, meta))
@@ -97,6 +106,34 @@ def test_conv_layer_bit_exact(mm, ishape, fhw, M, same, stride, shared):
     if not (stride > 1 and fhw == (1, 1)):
         ideal_gpu = host(server.idealFunctionality(dev(img), dev(filters), meta))
         assert np.array_equal(ideal_gpu.astype(object), ideal)
+
+
+def test_conv_exact_reshare_with_flood_noise(mm):
+    """t = 2^44 is the one ring size of CheetahLinear (base_mod < 2^45) where flood_ciphertext's noise
+    is not masked to zero by set_poly_coeffs_uniform's (1 << (bitlen % 64)) - 1 (bitlen = 63)."""
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    from tests.oracle_layers import flood_noise
+    t = 1 << 44
+    o, g = OracleCtx(N, (60, 49), t), mm.Context(N, (60, 49), t)
+    ishape, fshape, M = (3, 9, 9), (3, 3, 3), 2
+    cv, meta = ConvOracle(o, ishape, fshape, M, 1, 1, False), Meta(ishape, fshape, M, 1, 1, False)
+    sk, pk = keypair(o)
+    client, server = HomConv2DSS(), HomConv2DSS()
+    client.setUp(g, sk_ntt=dev(sk))
+    server.setUp(g, pk_ntt=dev(pk))
+    img, filters = uniform_mod(SEED + 1, ishape, t), signed_weights(SEED + 2, (M,) + fshape, 1 << 12, t)
+    a, e = rns_uniform(o, SEED + 3, cv.n_in, 2), noise(SEED + 4, (cv.n_in, N))
+    cts, f = cv.encrypt_image(sk, img, a, e), cv.encode_filters(filters)
+    u, e0, e1 = ternary(SEED + 5, (cv.n_out, N)), noise(SEED + 6, (cv.n_out, N)), noise(SEED + 7, (cv.n_out, N))
+    flood = splitmix64(SEED + 8, cv.n_out * N).reshape(cv.n_out, N)
+    words = splitmix64(SEED + 9, cv.n_out * N).reshape(cv.n_out, N)
+    assert flood_noise(o, flood[0]).any()
+    x_out, x_share = cv.server(cts, None, f, np.ascontiguousarray(pk[:, :1]), u, e1, words, exact=(flood, e0))
+    y_out, y_share = server.conv2DSS(dev(cts), None, dev(f), meta,
+                                     (dev(flood), dev(u), dev(e0), dev(e1), dev(words)), exact=True)
+    assert np.array_equal(host(y_out), x_out) and np.array_equal(host(y_share), x_share)
+    dec = host(client.decryptToTensor(y_out, meta))
+    assert np.array_equal((dec.astype(object) + x_share.astype(object)) % t, ideal_conv(img, filters, 1, 1, t))
 
 
 def test_conv_errors(mm):

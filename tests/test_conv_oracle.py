@@ -64,3 +64,26 @@ def test_resnet_layer_geometry():
     assert (th, tw) == (56, 56) and len(tg) == 3136
     f = cv.encode_filters(signed_weights(SEED, (1, 64, 3, 3), 1 << 12, T)[:1].repeat(64, 0)[:1].repeat(64, 0))
     assert int((f[0, 0] != 0).sum()) <= 9
+
+
+@pytest.mark.parametrize("logt", [37, 44])
+def test_conv_exact_reshare_flow_reconstructs(logt):
+    """USE_APPROX_RESHARE=0 build: sub_plain re-sharing, exact reconstruction (no +-1).  At t = 2^44
+    the flood noise is 63 bits wide; at the shipped 2^37 the reference's own mask makes it zero."""
+    from tests.oracle_binding import splitmix64
+    from tests.oracle_layers import flood_noise
+    N, t = 4096, 1 << logt
+    o = OracleCtx(N, (60, 49), t)
+    ishape, fshape, M = (3, 9, 9), (3, 3, 3), 2
+    cv = ConvOracle(o, ishape, fshape, M, 1, 1, False)
+    sk, pk = keypair(o)
+    img, filters = uniform_mod(SEED + 1, ishape, t), signed_weights(SEED + 2, (M,) + fshape, 1 << 12, t)
+    cts = cv.encrypt_image(sk, img, rns_uniform(o, SEED + 3, cv.n_in, 2), noise(SEED + 4, (cv.n_in, N)))
+    u, e0, e1 = ternary(SEED + 5, (cv.n_out, N)), noise(SEED + 6, (cv.n_out, N)), noise(SEED + 7, (cv.n_out, N))
+    flood = splitmix64(SEED + 8, cv.n_out * N).reshape(cv.n_out, N)
+    words = splitmix64(SEED + 9, cv.n_out * N).reshape(cv.n_out, N)
+    assert bool(flood_noise(o, flood[0]).any()) == (logt == 44)
+    out, share = cv.server(cts, None, cv.encode_filters(filters), np.ascontiguousarray(pk[:, :1]), u, e1, words,
+                           exact=(flood, e0))
+    dec = cv.decrypt(np.ascontiguousarray(sk[:1]), out)
+    assert np.array_equal((dec.astype(object) + share.astype(object)) % t, ideal_conv(img, filters, 1, 1, t))

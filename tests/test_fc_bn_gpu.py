@@ -66,6 +66,15 @@ def test_fc_layer_bit_exact(mm, rows, cols, shared):
     got_out, got_share = server.matVecMul(got_w, got_cts, got_s, meta, (dev(u), dev(e1), dev(mask)))
     assert np.array_equal(host(got_out), ref_out)
     assert np.array_equal(host(got_share), ref_share)
+    # USE_APPROX_RESHARE=0 build: bit-exact against the oracle, and the shares reconstruct exactly
+    flood, e0 = splitmix64(SEED + 9, fc.n_out * N).reshape(fc.n_out, N), noise(SEED + 10, (fc.n_out, N))
+    words = splitmix64(SEED + 11, fc.n_out * N).reshape(fc.n_out, N)
+    x_out, x_share = fc.server(ref_cts, ref_s, ref_w, np.ascontiguousarray(pk[:, :1]), u, e1, words, exact=(flood, e0))
+    y_out, y_share = server.matVecMul(got_w, got_cts, got_s, meta, (dev(flood), dev(u), dev(e0), dev(e1), dev(words)),
+                                      exact=True)
+    assert np.array_equal(host(y_out), x_out) and np.array_equal(host(y_share), x_share)
+    y_dec = host(client.decryptToVector(y_out, meta))
+    assert np.array_equal((y_dec.astype(object) + x_share.astype(object)) % T, (W.astype(object) @ vec.astype(object)) % T)
     got_dec = host(client.decryptToVector(got_out, meta))
     assert np.array_equal(got_dec, fc.decrypt(np.ascontiguousarray(sk[:1]), ref_out))
     ideal = (W.astype(object) @ vec.astype(object)) % T
