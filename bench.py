@@ -2,8 +2,8 @@
 """bench.py -- headline metric of BASELINE.json on N GPUs of one node.
 
 Step = one batched forward negacyclic NTT (N=4096, SEAL moduli {60,49} bits) over a
-resident batch of `--polys` two-limb polynomials (default 4096 polys = 8192 limb-NTTs =
-256 MiB, past the Infinity Cache).  Weak scaling: every rank transforms its own batch,
+resident batch of `--polys` two-limb polynomials (default 16384 polys = 32768 limb-NTTs =
+1 GiB, past the Infinity Cache).  Weak scaling: every rank transforms its own batch,
 no collective on the data path.  One JSON line on rank 0.
 """
 import argparse
@@ -17,6 +17,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_NTT = {4096: 65536, 8192: 131072}   # 2*N*8 B per limb-NTT
+BUTTERFLIES = {4096: 24576, 8192: 53248}       # (N/2) log2 N
+MADS_PER_BUTTERFLY = 9     # 64-bit Shoup multiply = 9 v_mad_u64_u32 (ntt kernel)
+MAD_PEAK = 34.5e12         # v_mad_u64_u32 lanes/s measured on MI355X (profiles/r01_a_valu_probe.txt)
+
+
+def pmc_traffic(ntts_per_launch):
+    """HBM bytes per launch of ntt_fwd_kernel<12> from the committed rocprofv3 --pmc passes
+    (tools/evidence.sh -> profiles/r01_ntt_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
+    MI355X_MICROARCH.md), scaled from the 8192 limb-NTTs per launch they were collected on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")) as f:
+            return json.load(f)["traffic_bytes"] * ntts_per_launch / 8192
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(seconds=12.0):
@@ -204,7 +218,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--polys", type=int, default=4096, help="two-limb polynomials per GPU per step")
+    ap.add_argument("--polys", type=int, default=16384, help="two-limb polynomials per GPU per step")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed NTT loop (for rocprofv3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -231,7 +246,7 @@ def main():
     achieved = ntts_per_step * BYTES_PER_NTT[4096] / launch_s
 
     extra = {}
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         _, inv_s = timed(lambda: ctx.ntt_inverse(data), max(5, args.steps // 5), 2, torch, None, 1)
         extra["intt4096_per_s"] = ntts_per_step / inv_s
         c8 = openmm_amd.Context(8192, (60, 60, 60, 49), 0, device=local)
@@ -247,9 +262,11 @@ def main():
         if world == 1:
             extra.update(layer_legs(torch, openmm_amd, local))
 
-    net = resnet50_leg(torch, dist, openmm_amd, local, world, rank)
+    if not args.headline_only:
+        net = resnet50_leg(torch, dist, openmm_amd, local, world, rank)
+        if rank == 0:
+            extra.update(net)
     if rank == 0:
-        extra.update(net)
         line = {
             "metric": "64-bit NTTs/sec (N=4096/8192) + ResNet50 HE-linear ms at 1/2/4/8 GPUs",
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
@@ -261,11 +278,16 @@ def main():
                        "polys_per_gpu": args.polys, "limbs": 2, "ntts_per_step_per_gpu": ntts_per_step,
                        "parallelism": f"independent batches x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "ntt_fwd_kernel<12>", "launch_us": launch_s * 1e6},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(ntts_per_step),
+                         "kernel": "ntt_fwd_kernel<12>", "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": ntts_per_step * BYTES_PER_NTT[4096],
+                         "int64_valu": {"achieved": ntts_per_step * BUTTERFLIES[4096] * MADS_PER_BUTTERFLY
+                                        / launch_s / 1e12, "peak": MAD_PEAK / 1e12, "unit": "T v_mad_u64_u32/s",
+                                        "frac": ntts_per_step * BUTTERFLIES[4096] * MADS_PER_BUTTERFLY
+                                        / launch_s / MAD_PEAK}},
             "extra": extra,
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
