@@ -128,25 +128,28 @@ __device__ __forceinline__ u64 make64(u32 lo, u32 hi) { return ((u64)hi << 32) |
 // the SGPR->VGPR copies; every instruction reads at most one SGPR.
 #define MMH_SHOUP_MAD_BODY(TW)                                                                        \
   const u32 x0 = lo32(x), x1 = hi32(x);                                                               \
-  u64 m, h, cy, cy2, t, acc;                                                                          \
+  u64 m, h, cy, cyd, t, acc;                                                                          \
   u32 h1, hi;                                                                                         \
-  asm("v_mad_u64_u32 %0, %2, %5, %6, 0\n\t"  /* m  = x1*s0                  */                        \
-      "v_mad_u64_u32 %0, %2, %4, %7, %0\n\t" /* m += x0*s1, carry -> cy     */                        \
-      "v_lshrrev_b64 %0, 32, %0\n\t"         /* m >>= 32                    */                        \
-      "v_mad_u64_u32 %1, %3, %5, %7, %0"       /* h  = x1*s1 + m              */                        \
-      : "=&v"(m), "=&v"(h), "=&s"(cy), "=&s"(cy2)                                                     \
-      : "v"(x0), "v"(x1), TW(lo32(wsh)), TW(hi32(wsh)));                                              \
-  asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(h1), "=s"(cy2) : "v"(hi32(h)), "s"(cy));           \
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %6\n\t" /* t  = base + x0*w0           */                        \
-      "v_mad_u64_u32 %0, %1, %4, %5, %0"       /* t += h0*nq0                 */                        \
-      : "=&v"(t), "=&s"(cy)                                                                           \
-      : "v"(x0), TW(lo32(w)), "v"(lo32(h)), "s"(lo32(nq)), "v"(base));                                \
-  asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\t"  /* cross terms, low 32 bits    */                        \
-      "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t"                                                          \
-      "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t"                                                          \
-      "v_mad_u64_u32 %0, %1, %8, %9, %0"                                                              \
-      : "=&v"(acc), "=&s"(cy)                                                                         \
-      : "v"(x0), TW(hi32(w)), "v"(x1), TW(lo32(w)), "v"(lo32(h)), "s"(hi32(nq)), "v"(h1), "s"(lo32(nq))); \
+  /* three independent chains interleaved so that no instruction waits on its predecessor:       */  \
+  /*   quotient  m = x1*s0 + x0*s1 (carry -> cy), h = x1*s1 + (m >> 32)                          */  \
+  /*   low word  t = base + x0*w0                                                                */  \
+  /*   cross     acc = x0*w1 + x1*w0   (only its low 32 bits are used)                           */  \
+  asm("v_mad_u64_u32 %0, %5, %7, %10, 0\n\t"                                                         \
+      "v_mad_u64_u32 %2, %5, %6, %8, %12\n\t"                                                        \
+      "v_mad_u64_u32 %0, %4, %6, %11, %0\n\t"                                                        \
+      "v_mad_u64_u32 %3, %5, %6, %9, 0\n\t"                                                          \
+      "v_lshrrev_b64 %0, 32, %0\n\t"                                                                 \
+      "v_mad_u64_u32 %3, %5, %7, %8, %3\n\t"                                                         \
+      "v_mad_u64_u32 %1, %5, %7, %11, %0"                                                              \
+      : "=&v"(m), "=&v"(h), "=&v"(t), "=&v"(acc), "=&s"(cy), "=&s"(cyd)                               \
+      : "v"(x0), "v"(x1), TW(lo32(w)), TW(hi32(w)), TW(lo32(wsh)), TW(hi32(wsh)), "v"(base));         \
+  /* h1 = hi(h) + carry; t += h0*nq0; acc += h0*nq1 + h1*nq0                                     */  \
+  asm("v_addc_co_u32_e64 %0, %3, 0, %4, %6\n\t"                                                      \
+      "v_mad_u64_u32 %1, %3, %5, %7, %1\n\t"                                                         \
+      "v_mad_u64_u32 %2, %3, %5, %8, %2\n\t"                                                         \
+      "v_mad_u64_u32 %2, %3, %0, %7, %2"                                                               \
+      : "=&v"(h1), "+v"(t), "+v"(acc), "=&s"(cyd)                                                     \
+      : "v"(hi32(h)), "v"(lo32(h)), "s"(cy), "s"(lo32(nq)), "s"(hi32(nq)));                           \
   /* opaque add: hipcc otherwise widens it to a 64-bit add of {0, acc} (three instructions) */        \
   asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"(hi32(t)), "v"(lo32(acc)));                              \
   return make64(lo32(t), hi);
