@@ -30,7 +30,10 @@ struct DevMod {
   u32 fold_c;                  // c, or 0 when q does not have that shape
   u32 fold_shift;              // b - 32
   u32 fold_mask;               // 2^(b-32) - 1
-  u32 pad_;
+  // q < 2^49: the NTT runs in double precision (exact integer arithmetic through FMA, ntt.hip) and
+  // the second word of every twiddle pair holds the bits of (double)w instead of the Shoup quotient
+  u32 f64;
+  double qd, qinv;             // (double)q and 1/q rounded to nearest
 };
 
 // A modulus without NTT tables (plain modulus t, BEHZ gamma): Barrett only.

@@ -2,6 +2,9 @@
 #include "common.hpp"
 #include "host_math.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace mmh {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
@@ -19,11 +22,21 @@ static void build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out, std::vector<ulo
   tables.resize(base + 2 * N);
   ulonglong2 *fwd = tables.data() + base, *inv = fwd + N;
   const u64 ipsi = inv_mod(psi, m);
+  // MMH_NTT_F64=0 keeps the integer butterflies for every modulus (A/B measurements, tests)
+  const char *env = getenv("MMH_NTT_F64");
+  const bool f64 = m < (u64(1) << 49) && !(env && env[0] == '0');
+  auto second = [&](u64 w) {
+    if (!f64) return shoup(w, m);
+    const double d = (double)w;  // exact: w < 2^49
+    u64 bits;
+    memcpy(&bits, &d, sizeof bits);
+    return bits;
+  };
   u64 p = 1, ip = 1;
   for (size_t k = 0; k < N; ++k) {
     const uint32_t r = bit_reverse((uint32_t)k, ctx->logN);
-    fwd[r] = make_ulonglong2(p, shoup(p, m));
-    inv[r] = make_ulonglong2(ip, shoup(ip, m));
+    fwd[r] = make_ulonglong2(p, second(p));
+    inv[r] = make_ulonglong2(ip, second(ip));
     p = mul_mod(p, psi, m);
     ip = mul_mod(ip, ipsi, m);
   }
@@ -38,7 +51,10 @@ static void build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out, std::vector<ulo
   // pseudo-Mersenne shape used by the NTT's partial reductions
   const int b = bit_count(m);
   const u64 c = b >= 64 ? 0 : (u64(1) << b) - m;
-  out->fold_c = out->fold_shift = out->fold_mask = out->pad_ = 0;
+  out->f64 = f64;
+  out->qd = (double)m;
+  out->qinv = 1.0 / (double)m;
+  out->fold_c = out->fold_shift = out->fold_mask = 0;
   if (b >= 32 && b <= 60 && c < (u64(1) << 31)) {
     // a folded value is at most 2^b - 1 + (2^(64-b) - 1)*c and must stay below 2q
     const u128 worst = ((u128)1 << b) - 1 + (u128)((u64(1) << (64 - b)) - 1) * c;

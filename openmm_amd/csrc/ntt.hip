@@ -116,6 +116,92 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 (&t
   }
 }
 
+
+// ---------------------------------------------------------------- double-precision butterflies
+// Moduli below 2^49 (SEAL's 49-bit q1, every BatchEncoder prime of constants.h:45-50) run their
+// butterflies on the FP64 pipe: v_fma_f64 / v_mul_f64 / v_add_f64 / v_rndne_f64 issue at the same
+// 4 cycles per wave64 as v_mad_u64_u32 (profiles/r01_f64_probe.txt) and a modular product needs 5 of
+// them instead of 12 integer instructions.  Values are signed integers held exactly in doubles:
+//   h = fl(w*y), l = w*y - h (exact, FMA), c = rint(h/q), d = h - c*q (exact: an integer below 2^53),
+//   w*y = c*q + (d + l) with |d + l| <= (1/2 + 3*B/16) q when |y| <= B*q, since q < 2^49.
+// Bound bookkeeping (B = magnitude bound in units of q, every intermediate must stay below 16q <= 2^53):
+//   forward  inputs centred to |v| <= 2; a stage maps B to B + 1/2 + 3B/16; the X operands are reduced
+//            to 1/2 at the first stage of passes B and C, so B peaks at 8.4 (N = 8192, end of pass A);
+//   inverse  inputs centred to |v| <= 1; sums are reduced every other stage, the fixed point of the
+//            recurrence is B = 2 at even stages, differences stay <= 8.
+// The final value is reduced to [0, q), so the visible result is that of the integer kernels.
+#pragma clang fp contract(off)
+struct F64Mod { double q, qinv; };
+__device__ __forceinline__ double f64_mulmod(double w, double y, const F64Mod &m) {
+  const double h = w * y;
+  const double l = __builtin_fma(w, y, -h);
+  const double c = __builtin_rint(h * m.qinv);
+  const double d = __builtin_fma(-c, m.q, h);
+  return d + l;
+}
+__device__ __forceinline__ double f64_reduce(double x, const F64Mod &m) {  // |result| <= q/2 (+1)
+  return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x);
+}
+// x < 2^52 as a double, minus `shift`: bias = 2^52 + shift (exact while shift < 2^52)
+__device__ __forceinline__ double f64_from_u64(u64 x, double bias) {
+  return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - bias;
+}
+__device__ __forceinline__ u64 f64_canonical(double v, const F64Mod &m) {  // v mod q in [0, q)
+  double r = f64_reduce(v, m);
+  r += r < 0.0 ? m.q : 0.0;
+  return (u64)__double_as_longlong(r + 0x1p52) & 0x000FFFFFFFFFFFFFull;
+}
+template <int R, int S0>
+__device__ __forceinline__ void load_twiddles_f64(const ulonglong2 *__restrict__ tw, u32 jhi,
+                                                  double (&w)[(1 << R) - 1]) {
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+#pragma unroll
+    for (int b = 0; b < (1 << u); ++b)
+      w[(1 << u) - 1 + b] = __longlong_as_double((long long)tw[(1u << (S0 + u)) + (jhi << u) + b].y);
+}
+// same index pattern as fwd_radix / inv_radix
+template <int R, bool REDUCE_FIRST>
+__device__ __forceinline__ void fwd_radix_f64(double (&x)[1 << R], const double (&tw)[(1 << R) - 1],
+                                              const F64Mod &m) {
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int b = 0; b < (1 << u); ++b) {
+      const double w = tw[(1 << u) - 1 + b];
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const int k0 = b * 2 * half + i, k1 = k0 + half;
+        const double X = (REDUCE_FIRST && u == 0) ? f64_reduce(x[k0], m) : x[k0];
+        const double T = f64_mulmod(w, x[k1], m);
+        x[k0] = X + T;
+        x[k1] = X - T;
+      }
+    }
+  }
+}
+template <int R, int E0>
+__device__ __forceinline__ void inv_radix_f64(double (&x)[1 << R], const double (&tw)[(1 << R) - 1],
+                                              const F64Mod &m) {
+#pragma unroll
+  for (int u = R - 1; u >= 0; --u) {
+    const int half = 1 << (R - 1 - u);
+    const int e = E0 + (R - 1 - u);
+#pragma unroll
+    for (int b = 0; b < (1 << u); ++b) {
+      const double w = tw[(1 << u) - 1 + b];
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const int k0 = b * 2 * half + i, k1 = k0 + half;
+        const double X = x[k0], Y = x[k1], S = X + Y;
+        x[k0] = (e & 1) ? f64_reduce(S, m) : S;
+        x[k1] = f64_mulmod(w, X - Y, m);
+      }
+    }
+  }
+}
+
 // Where a forward transform takes its input from.
 //   SRC_INPLACE  `data` itself.
 //   SRC_PLAIN    plaintext `src.p` [n_polys][N] with coefficients mod t, lifted on load into every
@@ -134,6 +220,107 @@ struct NttSource {
   int fw, origin, plane, row;      // coefficient = origin - cc*plane - r*row - col
 };
 
+// The EA = N/256 stride-256 coefficients of thread t, from wherever the transform reads them.
+template <int LOGN, int SRC>
+__device__ __forceinline__ void load_source(u64 (&x)[1 << (LOGN - 8)], const u64 *__restrict__ a,
+                                            const DevMod &M, const NttSource &src, int limbs, u64 *lds) {
+  constexpr int EA = 1 << (LOGN - 8);
+  const int t = threadIdx.x;
+  if (SRC == SRC_PLAIN) {
+    const u64 *__restrict__ m = src.p + (size_t)(blockIdx.x / limbs) * (1 << LOGN);
+    const u64 up = M.q - src.t;
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] = m[k * 256 + t];
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] += x[k] >= src.thr ? up : 0;
+  } else if (SRC == SRC_FILTER) {
+    const int poly = blockIdx.x / limbs, fm = poly / src.n_cslices, slice = poly % src.n_cslices;
+    const int nch = min(src.wc, src.C - slice * src.wc);
+    const u64 *__restrict__ taps = src.p + ((size_t)fm * src.C + (size_t)slice * src.wc) * src.taps;
+    const u64 up = M.q - src.t;
+#pragma unroll
+    for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = 0;
+    __syncthreads();
+    for (int i = t; i < nch * src.taps; i += 256) {
+      const int cc = i / src.taps, rc = i % src.taps, r = rc / src.fw, col = rc % src.fw;
+      u64 v = barrett128(0, taps[i], src.t, src.t_bhi, src.t_blo);
+      v += v >= src.thr ? up : 0;
+      lds[pad(src.origin - cc * src.plane - r * src.row - col)] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
+    __syncthreads();  // pass A of the double-precision body writes the same cells with another type
+  } else {
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
+  }
+}
+
+template <int LOGN>
+__device__ __forceinline__ void store_from_lds(u64 *__restrict__ a, const u64 *lds) {
+  ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(a);
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < (1 << LOGN) / 512; ++k) {
+    const int j = 2 * (k * 256 + t);
+    out[k * 256 + t] = make_ulonglong2(lds[pad(j)], lds[pad(j) + 1]);
+  }
+}
+
+// Forward transform of one limb with q < 2^49 in double precision; same passes and LDS image.
+template <int LOGN, int SRC>
+__device__ __forceinline__ void ntt_fwd_f64(u64 *__restrict__ a, const DevMod &M,
+                                            const ulonglong2 *__restrict__ tw, const NttSource &src,
+                                            int limbs, u64 *lds_u) {
+  constexpr int RA = LOGN - 8, EA = 1 << RA, REPS = (1 << LOGN) / 4096;
+  double *lds = reinterpret_cast<double *>(lds_u);
+  const int t = threadIdx.x;
+  const F64Mod m{M.qd, M.qinv};
+  double wB[15], wC[15];
+  {
+    u64 xi[EA];
+    load_source<LOGN, SRC>(xi, a, M, src, limbs, lds_u);
+    const double bias = 0x1p52 + 2.0 * m.q;  // inputs in [0, 4q) become |v| <= 2q
+    double x[EA];
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] = f64_from_u64(xi[k], bias);
+    double wA[EA - 1];
+    load_twiddles_f64<RA, 0>(tw, 0, wA);
+    load_twiddles_f64<4, RA>(tw, t >> 4, wB);
+    fwd_radix_f64<RA, false>(x, wA, m);
+#pragma unroll
+    for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = x[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rep = 0; rep < REPS; ++rep) {
+    const int g = t + 256 * rep, jhi = g >> 4, jlo = g & 15;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
+    if (rep > 0) load_twiddles_f64<4, RA>(tw, jhi, wB);
+    if (rep == REPS - 1) load_twiddles_f64<4, RA + 4>(tw, t, wC);
+    fwd_radix_f64<4, true>(x, wB, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rep = 0; rep < REPS; ++rep) {
+    const int g = t + 256 * rep;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[17 * g + k];
+    if (rep > 0) load_twiddles_f64<4, RA + 4>(tw, g, wC);
+    fwd_radix_f64<4, true>(x, wC, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds_u[17 * g + k] = f64_canonical(x[k], m);
+  }
+  __syncthreads();
+  store_from_lds<LOGN>(a, lds_u);
+}
+
 template <int LOGN, bool FOLD, int SRC = SRC_INPLACE>
 __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
@@ -144,42 +331,19 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
   const DevMod &M = mods[mod_base + blockIdx.x % limbs];
-  const Reducer<FOLD> rd(M);
-  const u64 nq = M.nq;
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
+  if (M.f64) {  // uniform over the workgroup
+    ntt_fwd_f64<LOGN, SRC>(a, M, tw, src, limbs, lds);
+    return;
+  }
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
 
   ulonglong2 wB[15], wC[15];
   {
     u64 x[EA];
-    if (SRC == SRC_PLAIN) {
-      const u64 *__restrict__ m = src.p + (size_t)(blockIdx.x / limbs) * N;
-      const u64 up = M.q - src.t;
-#pragma unroll
-      for (int k = 0; k < EA; ++k) x[k] = m[k * 256 + t];
-#pragma unroll
-      for (int k = 0; k < EA; ++k) x[k] += x[k] >= src.thr ? up : 0;
-    } else if (SRC == SRC_FILTER) {
-      const int poly = blockIdx.x / limbs, fm = poly / src.n_cslices, slice = poly % src.n_cslices;
-      const int nch = min(src.wc, src.C - slice * src.wc);
-      const u64 *__restrict__ taps = src.p + ((size_t)fm * src.C + (size_t)slice * src.wc) * src.taps;
-      const u64 up = M.q - src.t;
-#pragma unroll
-      for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = 0;
-      __syncthreads();
-      for (int i = t; i < nch * src.taps; i += 256) {
-        const int cc = i / src.taps, rc = i % src.taps, r = rc / src.fw, col = rc % src.fw;
-        u64 v = barrett128(0, taps[i], src.t, src.t_bhi, src.t_blo);
-        v += v >= src.thr ? up : 0;
-        lds[pad(src.origin - cc * src.plane - r * src.row - col)] = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
-    } else {
-#pragma unroll
-      for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
-    }
+    load_source<LOGN, SRC>(x, a, M, src, limbs, lds);
     ulonglong2 wA[EA - 1];
     load_twiddles<RA, 0>(tw, 0, wA);          // wave-uniform: scalar loads
     load_twiddles<4, RA>(tw, t >> 4, wB);     // for pass B (rep 0), in flight during pass A
@@ -213,11 +377,54 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
     for (int k = 0; k < 16; ++k) lds[17 * g + k] = rd.fwd_final(x[k]);
   }
   __syncthreads();
-  ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(a);
+  store_from_lds<LOGN>(a, lds);
+}
+
+// Inverse transform of one limb with q < 2^49 in double precision (LDS already holds the input).
+template <int LOGN>
+__device__ __forceinline__ void ntt_inv_f64(u64 *__restrict__ a, const DevMod &M,
+                                            const ulonglong2 *__restrict__ tw, u64 *lds_u) {
+  constexpr int RA = LOGN - 8, EA = 1 << RA, REPS = (1 << LOGN) / 4096;
+  double *lds = reinterpret_cast<double *>(lds_u);
+  const int t = threadIdx.x;
+  const F64Mod m{M.qd, M.qinv};
+  const double bias = 0x1p52 + m.q;  // inputs in [0, 2q) become |v| <= q
+  double wB[15], wC[15];
 #pragma unroll
-  for (int k = 0; k < N / 512; ++k) {
-    const int j = 2 * (k * 256 + t);
-    out[k * 256 + t] = make_ulonglong2(lds[pad(j)], lds[pad(j) + 1]);
+  for (int rep = 0; rep < REPS; ++rep) {
+    const int g = t + 256 * rep;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = f64_from_u64(lds_u[17 * g + k], bias);
+    load_twiddles_f64<4, RA + 4>(tw, g, wC);
+    if (rep == REPS - 1) load_twiddles_f64<4, RA>(tw, t >> 4, wB);
+    inv_radix_f64<4, 0>(x, wC, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[17 * g + k] = x[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rep = 0; rep < REPS; ++rep) {
+    const int g = t + 256 * rep, jhi = g >> 4, jlo = g & 15;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
+    if (rep > 0) load_twiddles_f64<4, RA>(tw, jhi, wB);
+    inv_radix_f64<4, 4>(x, wB, m);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
+  }
+  __syncthreads();
+  {
+    double x[EA];
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] = lds[pad(k * 256 + t)];
+    double wA[EA - 1];
+    load_twiddles_f64<RA, 0>(tw, 0, wA);
+    inv_radix_f64<RA, 8>(x, wA, m);
+    const double ninv = (double)M.ninv;  // exact: below q < 2^49
+#pragma unroll
+    for (int k = 0; k < EA; ++k) a[k * 256 + t] = f64_canonical(f64_mulmod(ninv, x[k], m), m);
   }
 }
 
@@ -230,8 +437,6 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
   const DevMod &M = mods[mod_base + blockIdx.x % limbs];
-  const Reducer<FOLD> rd(M);
-  const u64 nq = M.nq;
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset + N;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
@@ -244,6 +449,12 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     lds[pad(j) + 1] = v.y;
   }
   __syncthreads();
+  if (M.f64) {  // uniform over the workgroup
+    ntt_inv_f64<LOGN>(a, M, tw, lds);
+    return;
+  }
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
   ulonglong2 wB[15], wC[15];
 #pragma unroll
   for (int rep = 0; rep < REPS; ++rep) {

@@ -127,3 +127,31 @@ def test_worst_case_magnitudes(mm):
     d = to_device(ref + qs)            # inverse accepts < 2q
     g.ntt_inverse(d)
     assert np.array_equal(to_host(d), a)
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+@pytest.mark.parametrize("f64", ["1", "0"])
+def test_small_moduli_double_precision_and_integer_paths_agree(mm, N, f64, monkeypatch):
+    """moduli below 2^49 run their butterflies on the FP64 pipe (exact integers in doubles);
+    MMH_NTT_F64=0 keeps the integer butterflies: both must equal the oracle bit for bit, on
+    random data, on the all-(q-1) vector and on lazy inputs (forward < 4q, inverse < 2q)"""
+    from openmm_amd.lib import to_device, to_host
+    monkeypatch.setenv("MMH_NTT_F64", f64)
+    # SEAL's 49-bit primes of both degrees, the largest 48-bit and 33-bit NTT primes, the BOLE field prime of l=32
+    q = [562949953216513, 562949952847873, 281474976694273, 8589852673, 4293918721]
+    q = [m for m in q if m % (2 * N) == 1][:4]
+    assert len(q) >= 2
+    o, g = OracleCtx(N, q=q), mm.Context(N, q=q)
+    assert g.psi == o.psi
+    a = _polys(o, 6, SEED + 11)
+    qs = np.array(q, dtype=np.uint64)[None, :, None]
+    a[0] = np.broadcast_to(qs[0] - 1, a[0].shape)
+    a[1] = 0
+    a[1, :, N - 1] = 1
+    ref = o.ntt_forward(a)
+    d = to_device(a + qs * (splitmix64(SEED + 5, a.size).reshape(a.shape) % np.uint64(4)))
+    g.ntt_forward(d)
+    assert np.array_equal(to_host(d), ref)
+    d = to_device(ref + qs * (splitmix64(SEED + 6, a.size).reshape(a.shape) % np.uint64(2)))
+    g.ntt_inverse(d)
+    assert np.array_equal(to_host(d), a)

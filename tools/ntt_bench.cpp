@@ -1,6 +1,7 @@
 // Stand-alone driver of libmm_hip.so for profiling runs (rocprofv3 wants the program itself
 // after `--`).  Build: g++ -O2 tools/ntt_bench.cpp -Iinclude -Lopenmm_amd -lmm_hip -Wl,-rpath,'$ORIGIN/../openmm_amd' -o tools/ntt_bench
-// Usage: ntt_bench [logN=12] [polys=4096] [iters=20] [inverse=0]
+// Usage: ntt_bench [logN=12] [polys=4096] [iters=20] [inverse=0] [only_limb=-1]
+//   only_limb >= 0: a one-modulus context holding just that limb's prime (per-modulus kernel rates)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -12,12 +13,19 @@ int main(int argc, char **argv) {
   size_t polys = argc > 2 ? atol(argv[2]) : 4096;
   int iters = argc > 3 ? atoi(argv[3]) : 20;
   int inverse = argc > 4 ? atoi(argv[4]) : 0;
+  int only = argc > 5 ? atoi(argv[5]) : -1;
   size_t N = size_t(1) << logn, L = logn == 12 ? 2 : 4;
   int bits12[] = {60, 49}, bits13[] = {60, 60, 60, 49};
   mmh_ctx *ctx;
   CK(mmh_ctx_create_bits(&ctx, N, logn == 12 ? bits12 : bits13, L, 0, 0));
   uint64_t q[4];
   CK(mmh_ctx_info(ctx, nullptr, nullptr, q, nullptr, nullptr, nullptr));
+  if (only >= 0 && (size_t)only < L) {
+    const uint64_t one = q[only];
+    CK(mmh_ctx_destroy(ctx));
+    CK(mmh_ctx_create(&ctx, N, &one, 1, 0, 0));
+    q[0] = one, L = 1;
+  }
   std::vector<uint64_t> h(polys * L * N);
   uint64_t s = 0x4D264D;
   for (size_t i = 0; i < h.size(); ++i) {
