@@ -6,6 +6,8 @@
 #include "common.hpp"
 #include "geometry.hpp"
 
+#include <cstdlib>
+
 namespace mmh {
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
                  int mod_base, hipStream_t s);
@@ -40,6 +42,10 @@ struct mmh_conv_plan {
   uint32_t *d_tgt_dst = nullptr;         // [n_targets] offset inside one out_h x out_w plane
   uint32_t *d_tgt_slice = nullptr;       // [n_targets] spatial window the target belongs to
   uint8_t *d_keep = nullptr;             // [n_spatial][N] coefficients that survive remove_unused_coeffs
+  // 1x1 filters with few channels per polynomial: multiply-accumulate as a mod-q matrix product over
+  // channels (pointwise_mac below) instead of transforming M*Cs sparse filter polynomials
+  bool pointwise = false;
+  uint64_t *d_monomial_ntt = nullptr;    // [win_c][2][N]: NTT of X^(origin - c*plane); null when it is all ones
   std::vector<void *> allocs;
 };
 
@@ -127,6 +133,194 @@ int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t g
   return MMH_OK;
 }
 
+
+// ------------------------------------------------------------------ 1x1 filters, few channels per polynomial
+// EncodeFilter gives a 1x1 filter polynomial one monomial per channel of its slice:
+//   f[m][s] = sum_c w[m][s*wc + c] X^(origin - c*plane),
+// so  sum_s ct[s] * f[m][s]  =  sum_ch w[m][ch] * (ct[s(ch)] * X^(origin - c(ch)*plane))  over all channels.
+// In NTT form the bracket is U[ch] = NTT(ct[s(ch)]) (.) NTT(X^e) with a per-plan table of wc monomial
+// transforms, and the layer becomes the mod-q matrix product W[M x C] * U[C x columns] with scalar
+// weights: no filter polynomial is transformed or streamed (M*Cs*64 KiB in the dyadic form).  Everything is
+// exact mod q_l, so the result equals the per-term multiply_plain schedule bit for bit.  Cheaper than the
+// transform route while wc is small (C*4 instructions against Cs*(2 NTTs + MAC) per output column).
+constexpr int kPwMaxWc = 8;
+constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as w + 2^20
+
+// weights [M][C] (mod t) -> biased 32-bit form wp[C][Mpad], lifted 64-bit form wl[2][C][Mpad], and a flag
+// that is raised when some weight does not fit the fast form.  STRIDED: read them back from encoded
+// filter plaintexts instead of the raw tensor.
+template <bool FROM_PTS>
+__global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__ src, u32 *__restrict__ wp,
+                                                         u64 *__restrict__ wl, u32 *__restrict__ flag, int M,
+                                                         int Mpad, int C, int wc, int n_cslices, int logN,
+                                                         long origin, long plane, ModC t, u64 thr, u64 q0, u64 q1) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)C * Mpad) return;
+  const int m = (int)(idx % Mpad), ch = (int)(idx / Mpad);
+  u64 v = 0;
+  if (m < M) {
+    if (FROM_PTS) {
+      const int sl = ch / wc, c = ch % wc;
+      v = src[(((size_t)m * n_cslices + sl) << logN) + (origin - c * plane)];
+    } else {
+      v = red_t(src[(size_t)m * C + ch], t);
+    }
+  }
+  const bool neg = v >= thr;
+  const u64 mag = neg ? t.q - v : v;
+  if (mag >= (u64(1) << kPwBiasLog)) atomicOr(flag, 1u);
+  wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
+  wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
+  wl[(size_t)C * Mpad + idx] = neg ? v + (q1 - t.q) : v;         // limb 1
+}
+
+// U[ch][sp][p][l][i] = image[s(ch)*S + sp][p][l][i] * mono[c(ch)][l][i] mod q_l
+__global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ image, const u64 *__restrict__ mono,
+                                                        u64 *__restrict__ U, size_t total, int logN, size_t S, int wc,
+                                                        const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t N = size_t(1) << logN, i = idx & (N - 1);
+  const int l = (int)((idx >> logN) & 1), pl = (int)((idx >> logN) & 3);
+  const size_t row = idx >> (logN + 2), sp = row % S, ch = row / S;
+  const size_t sl = ch / wc, c = ch % wc;
+  const u64 x = image[(((sl * S + sp) * 4 + pl) << logN) + i];
+  U[idx] = mul_mod(x, mono[((c * 2 + l) << logN) + i], mods[l]);
+}
+
+// Two filters against both halves of one column value: four independent v_mad_u64_u32 in one asm
+// statement (hipcc pads every statement boundary), weights from SGPRs.
+__device__ __forceinline__ void mad_pair(u32 s_w0, u32 s_w1, u32 a0, u32 a1, u64 &x00, u64 &x01, u64 &x10,
+                                         u64 &x11) {
+  u64 carry;
+  asm("v_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+      "v_mad_u64_u32 %1, %4, %5, %8, %1\n\t"
+      "v_mad_u64_u32 %2, %4, %6, %7, %2\n\t"
+      "v_mad_u64_u32 %3, %4, %6, %8, %3"
+      : "+v"(x00), "+v"(x01), "+v"(x10), "+v"(x11), "=&s"(carry)
+      : "s"(s_w0), "s"(s_w1), "v"(a0), "v"(a1));
+}
+struct alignas(64) PwWeights16 { u32 v[16]; };
+
+// acc[m][col] = sum_ch W[m][ch] * U[ch][col] mod q_l.  One lane per column, 16 filters per wave, the four
+// waves of a workgroup share the column tile (their loads of U hit the same cache lines) and take
+// different filters, so the weights of a wave are uniform and come in through scalar loads.
+// Fast form: u = a0 + a1*2^30, acc0 += w'*a0, acc1 += w'*a1 with w' = w + 2^20 < 2^21: every sum of
+// <= 4096 terms stays below 2^63, one v_mad_u64_u32 each and no carries; the bias is removed at the end
+// with the column sums B0, B1:  sum w*u = (acc0 + acc1*2^30) - 2^20*(B0 + B1*2^30).
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ U, const u32 *__restrict__ wp,
+                                                      const u64 *__restrict__ wl, const u32 *__restrict__ flag,
+                                                      u64 *__restrict__ acc, int M, int Mpad, int C, size_t cols,
+                                                      int logN, const DevMod *__restrict__ mods) {
+  constexpr int TM = 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t col = (size_t)blockIdx.x * 64 + lane;
+  const int l = (int)((((size_t)blockIdx.x * 64) >> logN) & 1);
+  const int mbase = blockIdx.y * 64 + wave * TM;
+  if (mbase >= M) return;
+  const DevMod q = mods[l];
+  const u64 *__restrict__ up = U + col;
+  u64 res[TM];
+  if (*flag == 0) {
+    // weights of channel ch for this wave's 16 filters: one 64-byte scalar load, fetched one channel ahead
+    const PwWeights16 *__restrict__ w = reinterpret_cast<const PwWeights16 *>(wp + mbase);
+    const size_t wstep = (size_t)Mpad / TM;
+    u64 a0s[TM], a1s[TM], B0 = 0, B1 = 0;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) a0s[j] = a1s[j] = 0;
+    u64 un = up[0];
+    PwWeights16 wn = w[0];
+    for (int ch = 0; ch < C; ++ch) {
+      const u64 u = un;
+      const PwWeights16 wc = wn;
+      if (ch + 1 < C) {
+        un = up[(size_t)(ch + 1) * cols];
+        wn = w[(size_t)(ch + 1) * wstep];
+      }
+      const u32 a0 = (u32)u & 0x3fffffffu, a1 = (u32)(u >> 30);
+      B0 += a0, B1 += a1;
+#pragma unroll
+      for (int j = 0; j < TM; j += 2) mad_pair(wc.v[j], wc.v[j + 1], a0, a1, a0s[j], a1s[j], a0s[j + 1], a1s[j + 1]);
+    }
+    // bias term 2^20*(B0 + B1*2^30) mod q
+    const u64 blo = B0 + (B1 << 30), bhi = (B1 >> 34) + (blo < B0);
+    const u64 bias = reduce128_wide((bhi << kPwBiasLog) | (blo >> (64 - kPwBiasLog)), blo << kPwBiasLog, q);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const u64 lo = a0s[j] + (a1s[j] << 30), hi = (a1s[j] >> 34) + (lo < a0s[j]);
+      res[j] = sub_mod(reduce128_wide(hi, lo, q), bias, q.q);
+    }
+  } else {
+    // general weights: lifted 64-bit values, lazy 128-bit sums reduced every 8 terms (8 q^2 < q 2^64)
+    const u64 *__restrict__ w = wl + (size_t)l * C * Mpad + mbase;
+    u64 lo[TM], hi[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) lo[j] = hi[j] = 0;
+    for (int ch = 0; ch < C; ++ch) {
+      const u64 u = up[(size_t)ch * cols];
+      const u64 *__restrict__ wr = w + (size_t)ch * Mpad;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const u64 wj = wr[j], p = u * wj;
+        lo[j] += p;
+        hi[j] += mulhi64(u, wj) + (lo[j] < p);
+      }
+      if ((ch & 7) == 7) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) lo[j] = reduce128_wide(hi[j], lo[j], q), hi[j] = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) res[j] = reduce128_wide(hi[j], lo[j], q);
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+    if (mbase + j < M) acc[(size_t)(mbase + j) * cols + col] = res[j];
+}
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// acc[m*S + sp] (NTT form, [2][2][N] each) for all filters from the transformed image
+static int pointwise_mac(const mmh_conv_plan *p, const u64 *image_ntt, const u64 *d_filters_raw,
+                         const u64 *d_filter_pts, u64 *acc, hipStream_t s) {
+  const mmh_ctx *ctx = p->ctx;
+  const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
+  const int M = (int)p->meta.n_filters, Mpad = (M + 63) / 64 * 64, C = (int)p->f.c, wc = (int)p->split.win_c;
+  void *wp = nullptr, *wl = nullptr, *flag = nullptr, *U = nullptr;
+  int rc = MMH_OK;
+  auto grab = [&](void **b, size_t bytes) {
+    if (!rc && hipMallocAsync(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  };
+  grab(&wp, (size_t)C * Mpad * 4);
+  grab(&wl, (size_t)C * Mpad * 16);
+  grab(&flag, 4);
+  if (p->d_monomial_ntt) grab(&U, (size_t)C * cols * 8);
+  if (!rc && hipMemsetAsync(flag, 0, 4, s) != hipSuccess) rc = MMH_ERR_INTERNAL;
+  if (!rc) {
+    const long plane = p->split.win_h * p->split.win_w;
+    if (d_filters_raw)
+      hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)C * Mpad)), dim3(256), 0, s, d_filters_raw,
+                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, wc, (int)p->n_cslices, ctx->logN,
+                         p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+    else
+      hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)C * Mpad)), dim3(256), 0, s, d_filter_pts,
+                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, wc, (int)p->n_cslices, ctx->logN,
+                         p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+    if (U)
+      hipLaunchKernelGGL(pw_expand_kernel, dim3(nblk((size_t)C * cols)), dim3(256), 0, s, image_ntt,
+                         p->d_monomial_ntt, (u64 *)U, (size_t)C * cols, ctx->logN, S, wc, ctx->d_mods);
+    hipLaunchKernelGGL(pw_gemm_kernel, dim3((unsigned)(cols / 64), (unsigned)(Mpad / 64)), dim3(256), 0, s,
+                       U ? (const u64 *)U : image_ntt, (const u32 *)wp, (const u64 *)wl, (const u32 *)flag, acc, M,
+                       Mpad, C, cols, ctx->logN, ctx->d_mods);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  for (void *b : {wp, wl, flag, U})
+    if (b) (void)hipFreeAsync(b, s);
+  if (rc) set_error("pointwise_mac: launch or allocation failed");
+  return rc;
+}
+
 template <class T>
 static int upload_vec(mmh_conv_plan *p, const std::vector<T> &v, T **d) {
   MMH_HIP(hipMalloc((void **)d, std::max<size_t>(1, v.size()) * sizeof(T)));
@@ -134,7 +328,6 @@ static int upload_vec(mmh_conv_plan *p, const std::vector<T> &v, T **d) {
   if (!v.empty()) MMH_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return MMH_OK;
 }
-static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 }  // namespace mmh
 
 using namespace mmh;
@@ -247,6 +440,22 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     hoff += last_h;
   }
   p->n_targets = coef.size();
+  // 1x1 filters, few channels per polynomial: channel-wise matrix product (MMH_CONV_POINTWISE=0 keeps
+  // the transform route for A/B measurements)
+  const char *pw_env = getenv("MMH_CONV_POINTWISE");
+  p->pointwise = f.h == 1 && f.w == 1 && sp.win_c <= kPwMaxWc && in.c <= 4096 && ctx->L == 2 &&
+                 !(pw_env && pw_env[0] == '0');
+  if (p->pointwise && !(sp.win_c == 1 && p->filt_origin == 0)) {
+    std::vector<u64> mono((size_t)sp.win_c * 2 * N, 0);
+    for (long c = 0; c < sp.win_c; ++c)
+      for (int l = 0; l < 2; ++l) mono[((size_t)c * 2 + l) * N + (p->filt_origin - c * sp.win_h * sp.win_w)] = 1;
+    if ((rc = upload_vec(p, mono, &p->d_monomial_ntt)) ||
+        (rc = ntt_dispatch(ctx, false, p->d_monomial_ntt, (size_t)sp.win_c, 2, 0, nullptr))) {
+      mmh_conv_plan_destroy(p);
+      return rc;
+    }
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(MMH_ERR_INTERNAL, "monomial transform failed");
+  }
   if ((rc = upload_vec(p, wins, &p->d_windows)) || (rc = upload_vec(p, coef, &p->d_tgt_coef)) ||
       (rc = upload_vec(p, dst, &p->d_tgt_dst)) || (rc = upload_vec(p, slice, &p->d_tgt_slice)) ||
       (rc = upload_vec(p, keep, &p->d_keep))) {
@@ -337,7 +546,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   grab(&image, p->n_in * 4 * N * 8);
   grab(&acc, p->n_out * 4 * N * 8);
   grab(&zero, p->n_out * 2 * N * 8);
-  grab(&f_ntt, M * Cs * 2 * N * 8);
+  if (!p->pointwise) grab(&f_ntt, M * Cs * 2 * N * 8);
   // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
   if (!rc && p->meta.is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
   if (!rc && !p->meta.is_shared_input &&
@@ -345,13 +554,16 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     rc = MMH_ERR_INTERNAL;
   if (!rc) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
-  if (!rc && d_filters_raw)
+  if (!rc && p->pointwise)
+    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s);
+  if (!rc && !p->pointwise && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
                              p->split.win_w, 2, s);
-  if (!rc && !d_filters_raw) rc = ntt_lift_dispatch(ctx, d_filter_pts, (u64 *)f_ntt, M * Cs, 2, s);
+  if (!rc && !p->pointwise && !d_filters_raw) rc = ntt_lift_dispatch(ctx, d_filter_pts, (u64 *)f_ntt, M * Cs, 2, s);
   // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
-  if (!rc) rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, (const u64 *)f_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
+  if (!rc && !p->pointwise)
+    rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, (const u64 *)f_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
   if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
   // addRandomMask :761-788: flood_ciphertext (exact build: uniform noise on c0 first; mod-switch;
   // pk-encryption of zero, without e0 in the approximate build),

@@ -21,6 +21,11 @@ CASES = [
     ((3, 230, 230), (7, 7), 2, 0, 2, False),   # ResNet50 conv1 geometry (Appendix D), 2 filters
     ((8, 9, 11), (2, 3), 3, 1, 1, True),       # fh != fw: FilterIndexer reads "h" from the width (Appendix B)
     ((130, 7, 7), (1, 1), 2, 0, 1, True),      # 83 channels per polynomial, ragged last channel slice
+    # 1x1 filters with few channels per polynomial take the channel-wise matrix-product route:
+    ((6, 56, 56), (1, 1), 3, 0, 1, True),      # one channel per polynomial (constant filter polynomials)
+    ((12, 28, 28), (1, 1), 4, 0, 1, True),     # five channels per polynomial, ragged last slice (5 + 5 + 2)
+    ((2, 70, 70), (1, 1), 2, 0, 1, False),     # spatial windows as well
+    ((7, 56, 56), (1, 1), 70, 0, 2, True),     # stride trick (28x28 after subsampling), more than 64 filters
 ]
 
 
@@ -40,6 +45,30 @@ def dev(a):
 
 def host(t):
     return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("wbound", [1 << 12, 1 << 36])
+def test_pointwise_route_general_weights(mm, wbound):
+    """1x1 route with weights up to the whole ring (|w| < 2^36 leaves its 21-bit fast form) against the
+    transform route on the same plan inputs; both must also equal the oracle's per-term schedule"""
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    ishape, fshape, M = (11, 28, 28), (11, 1, 1), 5
+    o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
+    cv, meta = ConvOracle(o, ishape, fshape, M, 0, 1, True), Meta(ishape, fshape, M, 0, 1, True)
+    sk, pk = keypair(o)
+    server = HomConv2DSS()
+    server.setUp(g, pk_ntt=dev(pk))
+    share0, share1 = uniform_mod(SEED + 1, ishape, T), uniform_mod(SEED + 2, ishape, T)
+    filters = signed_weights(SEED + 3, (M,) + fshape, wbound, T)
+    a, e = rns_uniform(o, SEED + 4, cv.n_in, 2), noise(SEED + 5, (cv.n_in, N))
+    cts, f, s1 = cv.encrypt_image(sk, share0, a, e), cv.encode_filters(filters), cv.encode_image(share1)
+    u, e1 = ternary(SEED + 6, (cv.n_out, N)), noise(SEED + 7, (cv.n_out, N))
+    mask = rns_uniform(o, SEED + 8, cv.n_out, 1)[:, 0]
+    ref_out, ref_share = cv.server(cts, s1, f, np.ascontiguousarray(pk[:, :1]), u, e1, mask)
+    rand = (dev(u), dev(e1), dev(mask))
+    for got in (server.conv2DSS(dev(cts), dev(s1), dev(f), meta, rand),
+                server.conv2DSSFromWeights(dev(cts), dev(s1), dev(filters), meta, rand)):
+        assert np.array_equal(host(got[0]), ref_out) and np.array_equal(host(got[1]), ref_share)
 
 
 @pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", CASES)
