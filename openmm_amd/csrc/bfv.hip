@@ -8,6 +8,8 @@
 namespace mmh {
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
                  int mod_base, hipStream_t s);
+int ntt_signed_dispatch(const mmh_ctx *ctx, const int64_t *d_src, u64 *d_out, size_t n_polys, int limbs,
+                        hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
 
@@ -313,6 +315,40 @@ __global__ __launch_bounds__(256) void truncate_kernel(u64 *__restrict__ cts, si
   *c1 &= mask1;
 }
 
+// Re-sharing tail of the approximate build, one pass per output ciphertext (hom_conv2d_ss.cc:761-788,
+// :392-441, :108-140): out = truncate(mod_switch(acc) + zero + (0, e1) - (mask, 0)) with the unused
+// coefficients of c0 cleared.  acc [n][2][2][N] coefficient form at the first level; zero [n][2][N] the
+// noiseless pk-encryption of zero at the last level; mask [n][N] mod q0; e1 signed.
+__global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ zero,
+                                                             const int64_t *__restrict__ e1,
+                                                             const u64 *__restrict__ mask, u64 *__restrict__ out,
+                                                             size_t total, int logN, u64 inv_qlast, u64 mask0,
+                                                             u64 mask1, const uint8_t *__restrict__ keep,
+                                                             size_t keep_period, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  if (idx >= total) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const DevMod &q0 = mods[0];
+  const u64 q1 = mods[1].q, half = q1 >> 1, half0 = reduce64(half, q0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const size_t p = k * 2 + j;
+    u64 last = csub(acc[((p * 2 + 1) << logN) + i] + half, q1);          // divide_and_round_q_last
+    const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
+    u64 v = mul_mod(sub_mod(acc[((p * 2) << logN) + i], tmp, q0.q), inv_qlast, q0);
+    v = add_mod(v, zero[(p << logN) + i], q0.q);
+    if (j == 1) {
+      if (e1) v = add_mod(v, signed_to_mod(e1[idx], q0.q), q0.q);
+      v &= mask1;
+    } else {
+      v = sub_mod(v, mask[idx], q0.q);
+      const bool kept = !keep || keep[((k % keep_period) << logN) + i];
+      v = kept ? (v & mask0) : 0;
+    }
+    out[(p << logN) + i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void slot_scatter_kernel(const u64 *__restrict__ vals, u64 *__restrict__ pts,
                                                            size_t total, int logN, const u32 *__restrict__ map,
                                                            ModC t) {
@@ -592,6 +628,33 @@ extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t
          ctx->bfv.mask1, d_keep, keep_period ? keep_period : 1);
   return MMH_OK;
 }
+
+// addRandomMask + truncate_for_decryption + removeUnusedCoeffs of the shipped USE_APPROX_RESHARE build
+// (hom_conv2d_ss.cc:761-788, :698-703, :800-851; hom_fc_ss.cc:473-561) on n accumulated ciphertexts:
+// d_acc [n][2][2][N] in NTT form at the first level (consumed), d_out [n][2][N] at the last level.
+// Six launches: inverse NTT of acc, forward NTT of u straight from the signed samples, pk product,
+// inverse NTT, and one pass that mod-switches, adds the encryption of zero and e1, subtracts the mask,
+// truncates and clears the unused coefficients.  Same bits as the step-by-step entry points.
+namespace mmh {
+int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
+                        const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
+                        u64 *d_out, hipStream_t s) {
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  const size_t N = ctx->N;
+  StreamBuf u(s), zero(s);
+  MMH_HIP(u.alloc(n * N * 8));
+  MMH_HIP(zero.alloc(n * 2 * N * 8));
+  CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
+  CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
+  LAUNCH(mul_pk_kernel, n * N, s, u.as<u64>(), d_pk_ntt_last, zero.as<u64>(), n * N, ctx->logN, 1, ctx->d_mods);
+  CHECK_RC(ntt_dispatch(ctx, true, zero.as<u64>(), n * 2, 1, 0, s));
+  LAUNCH(reshare_finish_kernel, n * N, s, d_acc, zero.as<u64>(), d_e1, d_mask, d_out, n * N, ctx->logN,
+         ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep, keep_period ? keep_period : 1,
+         ctx->d_mods);
+  return MMH_OK;
+}
+}  // namespace mmh
 
 extern "C" int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts,
                                 void *stream) {

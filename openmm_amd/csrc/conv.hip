@@ -13,6 +13,9 @@ int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys,
                  int mod_base, hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
+int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
+                        const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
+                        u64 *d_out, hipStream_t s);
 int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
                         int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
                         hipStream_t s);
@@ -143,7 +146,7 @@ int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t g
 // weights: no filter polynomial is transformed or streamed (M*Cs*64 KiB in the dyadic form).  Everything is
 // exact mod q_l, so the result equals the per-term multiply_plain schedule bit for bit.  Cheaper than the
 // transform route while wc is small (C*4 instructions against Cs*(2 NTTs + MAC) per output column).
-constexpr int kPwMaxWc = 8;
+constexpr int kPwMaxWc = 24;  // measured break-even near 28 channels per polynomial
 constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as w + 2^20
 
 // weights [M][C] (mod t) -> biased 32-bit form wp[C][Mpad], lifted 64-bit form wl[2][C][Mpad], and a flag
@@ -545,7 +548,6 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   };
   grab(&image, p->n_in * 4 * N * 8);
   grab(&acc, p->n_out * 4 * N * 8);
-  grab(&zero, p->n_out * 2 * N * 8);
   if (!p->pointwise) grab(&f_ntt, M * Cs * 2 * N * 8);
   // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
   if (!rc && p->meta.is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
@@ -564,30 +566,31 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
   if (!rc && !p->pointwise)
     rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, (const u64 *)f_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
-  if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
-  // addRandomMask :761-788: flood_ciphertext (exact build: uniform noise on c0 first; mod-switch;
-  // pk-encryption of zero, without e0 in the approximate build),
-  if (!rc && exact) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
-  if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
-  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
-  if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
-  // ... sample_random_mask + sub_poly_inplace, share scattered into the tensor.  Approximate build: the
-  // mask is an RNS polynomial and the share its scale-and-round; exact build: the mask is a plaintext
-  // mod t, subtracted by sub_plain, and the share is the mask itself (:225-272)
-  if (!rc && !exact) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
-  if (!rc && !exact)
-    rc = launch_share_from_mask(ctx, d_mask, d_out_share, M, p->n_targets, S, (size_t)(p->out_h * p->out_w),
-                                p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  if (!rc && !exact) {
+    // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
+    // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
+    rc = reshare_tail_approx(ctx, (u64 *)acc, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S, d_out_cts, s);
+    if (!rc)
+      rc = launch_share_from_mask(ctx, d_mask, d_out_share, M, p->n_targets, S, (size_t)(p->out_h * p->out_w),
+                                  p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  }
   if (exact) {
+    // USE_APPROX_RESHARE=0: uniform noise on c0 first, e0 kept, the mask is a plaintext mod t subtracted
+    // by sub_plain and the share is the mask itself (:225-272, :358-380)
+    grab(&zero, p->n_out * 2 * N * 8);
     grab(&mask_t, p->n_out * N * 8);
+    if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
+    if (!rc) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
+    if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
+    if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
+    if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
     if (!rc) rc = mmh_reduce_mod_t(ctx, d_mask, (u64 *)mask_t, p->n_out * N, stream);
     if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)mask_t, p->n_out, 1, d_out_cts, stream);
     if (!rc)
       rc = launch_gather_targets(ctx, (const u64 *)mask_t, d_out_share, M, p->n_targets, S,
                                  (size_t)(p->out_h * p->out_w), p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+    if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, S, stream);
   }
-  // truncate_for_decryption :698-703 and removeUnusedCoeffs :800-851 in one pass
-  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, S, stream);
   cleanup();
   return rc;
 }

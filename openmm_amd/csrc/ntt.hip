@@ -211,7 +211,10 @@ __device__ __forceinline__ void inv_radix_f64(double (&x)[1 << R], const double 
 //                (tensor_encoder.cc EncodeFilter: tap (cc, r, col) -> coefficient
 //                origin - cc*plane - r*row - col), so neither the sparse plaintexts nor their
 //                lifted images exist in memory.
-enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2 };
+//   SRC_SIGNED   small signed polynomials `src.p` [n_polys][N] (int64: ternary u, noise), mapped to
+//                [0, q) per limb on load (sample_poly_ternary / SEAL_NOISE_SAMPLER outputs as
+//                encrypt_zero consumes them, hom_conv2d_ss.cc:302-306).
+enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3 };
 struct NttSource {
   const u64 *p;
   u64 t, thr;                      // plain modulus and the lift threshold (t + 1) / 2
@@ -233,6 +236,14 @@ __device__ __forceinline__ void load_source(u64 (&x)[1 << (LOGN - 8)], const u64
     for (int k = 0; k < EA; ++k) x[k] = m[k * 256 + t];
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] += x[k] >= src.thr ? up : 0;
+  } else if (SRC == SRC_SIGNED) {
+    const long long *__restrict__ m =
+        reinterpret_cast<const long long *>(src.p) + (size_t)(blockIdx.x / limbs) * (1 << LOGN);
+#pragma unroll
+    for (int k = 0; k < EA; ++k) {
+      const long long v = m[k * 256 + t];
+      x[k] = v >= 0 ? (u64)v : M.q - (u64)(-v);
+    }
   } else if (SRC == SRC_FILTER) {
     const int poly = blockIdx.x / limbs, fm = poly / src.n_cslices, slice = poly % src.n_cslices;
     const int nch = min(src.wc, src.C - slice * src.wc);
@@ -509,6 +520,8 @@ static int launch(int mode, bool fold, u64 *d, const mmh_ctx *ctx, size_t blocks
                   ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_PLAIN> : ntt_fwd_kernel<LOGN, false, SRC_PLAIN>)
               : mode == SRC_FILTER
                   ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_FILTER> : ntt_fwd_kernel<LOGN, false, SRC_FILTER>)
+              : mode == SRC_SIGNED
+                  ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_SIGNED> : ntt_fwd_kernel<LOGN, false, SRC_SIGNED>)
                   : (fold ? ntt_fwd_kernel<LOGN, true, SRC_INPLACE> : ntt_fwd_kernel<LOGN, false, SRC_INPLACE>);
   if (lds_bytes<LOGN>() > 48 * 1024)  // per device and cheap: set on every launch
     MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -539,6 +552,14 @@ int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n
   NttSource src{};
   src.p = d_src, src.t = ctx->t, src.thr = ctx->bfv.thr;
   return dispatch(ctx, SRC_PLAIN, d_out, src, n_polys, limbs, 0, s);
+}
+
+// out[k][l] = NTT_l(src[k] mod q_l) for the first `limbs` moduli, src [n_polys][N] signed
+int ntt_signed_dispatch(const mmh_ctx *ctx, const int64_t *d_src, u64 *d_out, size_t n_polys, int limbs,
+                        hipStream_t s) {
+  NttSource src{};
+  src.p = reinterpret_cast<const u64 *>(d_src);
+  return dispatch(ctx, SRC_SIGNED, d_out, src, n_polys, limbs, 0, s);
 }
 
 // out[m*n_cslices + slice][l] = NTT_l(lift_l(EncodeFilter(filters[m], slice))), filters [M][C][fh][fw]

@@ -117,7 +117,7 @@ class HomConv2DSS:
         L.check(self.ctx.lib.mmh_conv_encode_filters(p.handle, L.dptr(filters), L.dptr(out), L._stream_ptr()))
         # a filter encodes to all-zero polynomials iff all its weights are 0 mod t: settle the
         # conv2DOneFilter :573-580 check here, on the small tensor, and remember the verdict
-        out._mm_nonzero = bool((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
+        out._mm_nonzero = L.DeferredFlag((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
         return out
 
     # conv2DSS (hom_conv2d_ss.cc:621-712); rand = (u [n_out,N], e1 [n_out,N], mask [n_out,N]) for the
@@ -130,10 +130,10 @@ class HomConv2DSS:
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
         # conv2DOneFilter :573-580: a filter whose polynomials are all zero is an error
+        # (the verdict is read after the layer's kernels are enqueued; on error the outputs are dropped)
         nz = getattr(filters, "_mm_nonzero", None)
         if nz is None:  # polynomials that did not come from encodeFilters: look at them
-            nz = bool((filters.reshape(meta.n_filters, -1) != 0).any(dim=1).all())
-        self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
+            nz = L.DeferredFlag((filters.reshape(meta.n_filters, -1) != 0).any(dim=1).all())
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)
         if exact:
@@ -143,12 +143,13 @@ class HomConv2DSS:
                                                        L.dptr(filters), L.dptr(self.pk_last), L.dptr(flood),
                                                        L.dptr(u), L.dptr(e0), L.dptr(e1), L.dptr(mask),
                                                        L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
-            return out_cts, out_share
-        u, e1, mask = rand
-        L.check(self.ctx.lib.mmh_conv_server(p.handle, L.dptr(img_share0),
-                                             L.dptr(img_share1 if meta.is_shared_input else None),
-                                             L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
-                                             L.dptr(mask), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        else:
+            u, e1, mask = rand
+            L.check(self.ctx.lib.mmh_conv_server(p.handle, L.dptr(img_share0),
+                                                 L.dptr(img_share1 if meta.is_shared_input else None),
+                                                 L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
+                                                 L.dptr(mask), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        self._need(bool(nz), 8, "conv2DOneFilter: filter with all zero is not supported")
         return out_cts, out_share
 
     # encodeFilters + conv2DSS as CheetahLinear::conv2d chains them (cheetah-api.cpp:417-445), in one
@@ -161,8 +162,7 @@ class HomConv2DSS:
         self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
-        nz = bool((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
-        self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
+        nz = L.DeferredFlag((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
         u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)
@@ -171,6 +171,7 @@ class HomConv2DSS:
                                                      L.dptr(filters.contiguous()), L.dptr(self.pk_last), L.dptr(u),
                                                      L.dptr(e1), L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
                                                      L._stream_ptr()))
+        self._need(bool(nz), 8, "conv2DOneFilter: filter with all zero is not supported")
         return out_cts, out_share
 
     # decryptToTensor (hom_conv2d_ss.cc:853-941)

@@ -86,7 +86,7 @@ class HomFCSS:
         from .hom_conv2d_ss import _mod_t
         d0, d1 = p.split
         nz = F.pad(_mod_t(w, self.ctx.t) != 0, (0, p.n_in * d1 - w.shape[1], 0, p.n_out * d0 - w.shape[0]))
-        out._mm_nonzero = bool(nz.view(p.n_out, d0, p.n_in, d1).any(dim=3).any(dim=1).all())
+        out._mm_nonzero = L.DeferredFlag(nz.view(p.n_out, d0, p.n_in, d1).any(dim=3).any(dim=1).all())
         return out
 
     # :394-471; rand = (u, e1, mask) or, exact=True (USE_APPROX_RESHARE=0 build), (flood, u, e0, e1, mask)
@@ -98,8 +98,7 @@ class HomFCSS:
         # :414-422: a sub-matrix that encodes to zero is rejected
         nz = getattr(matrix, "_mm_nonzero", None)
         if nz is None:
-            nz = bool((matrix != 0).any(dim=2).all())
-        self._need(nz, 7, "matVecMul: sub-matrix with all zero is not supported")
+            nz = L.DeferredFlag((matrix != 0).any(dim=2).all())
         if meta.is_shared_input:
             self._need(vec_share1 is not None and vec_share1.shape[0] == p.n_in, 3, "matVecMul: #shares")
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
@@ -111,12 +110,13 @@ class HomFCSS:
                                                      L.dptr(matrix), L.dptr(self.pk_last), L.dptr(flood), L.dptr(u),
                                                      L.dptr(e0), L.dptr(e1), L.dptr(mask), L.dptr(out_cts),
                                                      L.dptr(out_share), L._stream_ptr()))
-            return out_cts, out_share
-        u, e1, mask = rand
-        L.check(self.ctx.lib.mmh_fc_server(p.handle, L.dptr(vec_share0),
-                                           L.dptr(vec_share1 if meta.is_shared_input else None), L.dptr(matrix),
-                                           L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),
-                                           L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        else:
+            u, e1, mask = rand
+            L.check(self.ctx.lib.mmh_fc_server(p.handle, L.dptr(vec_share0),
+                                               L.dptr(vec_share1 if meta.is_shared_input else None), L.dptr(matrix),
+                                               L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),
+                                               L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        self._need(bool(nz), 7, "matVecMul: sub-matrix with all zero is not supported")
         return out_cts, out_share
 
     def decryptToVector(self, enc_vector, meta):  # :572-602

@@ -136,6 +136,24 @@ def _stream_ptr():
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
+class DeferredFlag:
+    """A boolean verdict computed on the device and read back without draining the launch queue:
+    the value is copied to pinned host memory right away, the caller enqueues its kernels, and only
+    then waits for that early copy (not for the kernels behind it).  The reference decides the same
+    conditions on host data before it starts (hom_conv2d_ss.cc:573-580, hom_fc_ss.cc:414-422)."""
+
+    def __init__(self, flag_dev):
+        import torch
+        self.host = torch.empty((), dtype=torch.bool, pin_memory=True)
+        self.host.copy_(flag_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def __bool__(self):
+        self.event.synchronize()
+        return bool(self.host)
+
+
 def dptr(t):
     """Device pointer of a contiguous torch CUDA tensor (None -> NULL)."""
     if t is None:

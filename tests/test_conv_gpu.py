@@ -184,6 +184,20 @@ def test_conv_errors(mm):
     with pytest.raises(mm.MMHError) as ei:   # no public key -> ERR_CONFIG
         h.conv2DSS(None, None, None, meta, None)
     assert ei.value.code == 1
+    # a filter that is all zero mod t -> ERR_INVALID_ARG (conv2DOneFilter, hom_conv2d_ss.cc:573-580)
+    h.setUp(g, pk_ntt=torch.zeros((2, 2, N), dtype=torch.int64, device="cuda"))
+    p = h.plan(meta)
+    filters = torch.ones((2, 3, 3, 3), dtype=torch.int64, device="cuda")
+    filters[1] = T   # zero mod t
+    cts = torch.zeros((p.n_in, 2, 2, N), dtype=torch.int64, device="cuda")
+    s1 = torch.zeros((p.n_in, N), dtype=torch.int64, device="cuda")
+    z = torch.zeros((p.n_out, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(mm.MMHError) as ei:
+        h.conv2DSSFromWeights(cts, s1, filters, meta, (z, z, z))
+    assert ei.value.code == 8
+    with pytest.raises(mm.MMHError) as ei:
+        h.conv2DSS(cts, s1, h.encodeFilters(filters, meta), meta, (z, z, z))
+    assert ei.value.code == 8
 
 
 def test_sharded_conv_single_rank_equals_unsharded(mm):

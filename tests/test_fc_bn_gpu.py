@@ -92,8 +92,9 @@ def test_fc_rejects_zero_block(mm):
     p = h.plan(meta)
     w = torch.zeros((p.n_out, p.n_in, N), dtype=torch.int64, device="cuda")
     cts = torch.zeros((p.n_in, 2, 2, N), dtype=torch.int64, device="cuda")
-    with pytest.raises(mm.MMHError) as ei:
-        h.matVecMul(w, cts, None, meta, (None, None, None))
+    z = torch.zeros((p.n_out, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(mm.MMHError) as ei:   # the verdict is read back after the kernels are enqueued
+        h.matVecMul(w, cts, None, meta, (z, z, z))
     assert ei.value.code == 7  # ERR_INVALID_ARG, hom_fc_ss.cc:419
 
 
