@@ -57,6 +57,10 @@ int mmh_ctx_info(const mmh_ctx *ctx, size_t *N, size_t *L, uint64_t *q /*L*/, ui
 /* ---- device memory helpers for C/C++ callers that do not link HIP themselves */
 int mmh_malloc(void **d_ptr, size_t bytes);
 int mmh_free(void *d_ptr);
+/* Layer calls keep their scratch buffers cached between calls (reused in stream order, no per-call
+ * allocation once warm).  This returns the cached blocks of the current device to the driver after a
+ * device synchronisation.  No counterpart in the reference (SEAL's MemoryPool plays that role there). */
+int mmh_scratch_release(void);
 int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int mmh_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
 int mmh_memset(void *d_dst, int value, size_t bytes, void *stream);

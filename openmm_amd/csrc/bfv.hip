@@ -13,14 +13,14 @@ int ntt_signed_dispatch(const mmh_ctx *ctx, const int64_t *d_src, u64 *d_out, si
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
 
-// stream-ordered scratch buffer
+// call-scoped scratch buffer (stream-ordered reuse, see scratch_alloc)
 struct StreamBuf {
   void *p = nullptr;
   hipStream_t s;
   explicit StreamBuf(hipStream_t st) : s(st) {}
-  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 1, s); }
+  hipError_t alloc(size_t bytes) { return scratch_alloc(&p, bytes ? bytes : 1, s); }
   ~StreamBuf() {
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)scratch_free(p, s);
   }
   template <class T>
   T *as() { return reinterpret_cast<T *>(p); }

@@ -65,6 +65,10 @@ struct BfvConsts {
 };
 
 void set_error(const std::string &msg);
+// call-scoped device scratch from a cache of blocks reused in stream order (context.hip); same
+// calling convention as hipMallocAsync / hipFreeAsync
+hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t s);
+hipError_t scratch_free(void *p, hipStream_t s);
 
 #define MMH_FAIL(code, msg)                                                    \
   do {                                                                         \

@@ -4,10 +4,87 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace mmh {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+// ---------------------------------------------------------------- scratch cache
+// Layer calls need scratch (transformed operands, accumulators) for the length of the call.  hipMallocAsync /
+// hipFreeAsync cost 15-22 us each on the host here (profiles/r01_hip_api_small_layer.csv), more than the
+// kernels of a small layer, so freed blocks are kept in a process-wide list tagged with device and stream:
+// a block is only handed out again on the stream it was last used on, where stream order already makes
+// the reuse safe; no event and no synchronisation.  mmh_scratch_release() returns everything to the driver.
+struct ScratchBlock {
+  void *p;
+  size_t bytes;
+  int device;
+  hipStream_t stream;
+};
+static std::mutex g_scratch_mu;
+static std::vector<ScratchBlock> g_scratch_free;
+static std::unordered_map<void *, ScratchBlock> g_scratch_live;
+
+static void scratch_drop_free(int device) {  // caller holds the lock and has synchronised the device
+  size_t w = 0;
+  for (size_t i = 0; i < g_scratch_free.size(); ++i) {
+    if (device < 0 || g_scratch_free[i].device == device) {
+      (void)hipFree(g_scratch_free[i].p);
+    } else {
+      g_scratch_free[w++] = g_scratch_free[i];
+    }
+  }
+  g_scratch_free.resize(w);
+}
+
+hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t s) {
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  size_t best = g_scratch_free.size();
+  for (size_t i = 0; i < g_scratch_free.size(); ++i) {
+    const ScratchBlock &b = g_scratch_free[i];
+    if (b.device != device || b.stream != s || b.bytes < bytes || b.bytes > 2 * bytes + (size_t(1) << 20)) continue;
+    if (best == g_scratch_free.size() || b.bytes < g_scratch_free[best].bytes) best = i;
+  }
+  ScratchBlock blk;
+  if (best < g_scratch_free.size()) {
+    blk = g_scratch_free[best];
+    g_scratch_free[best] = g_scratch_free.back();
+    g_scratch_free.pop_back();
+  } else {
+    void *q = nullptr;
+    e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {  // give the cached blocks back and try once more
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      scratch_drop_free(device);
+      e = hipMalloc(&q, bytes);
+      if (e != hipSuccess) return e;
+    }
+    blk = ScratchBlock{q, bytes, device, s};
+  }
+  blk.stream = s;
+  g_scratch_live[blk.p] = blk;
+  *p = blk.p;
+  return hipSuccess;
+}
+
+hipError_t scratch_free(void *p, hipStream_t s) {
+  if (!p) return hipSuccess;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch_live.find(p);
+  if (it == g_scratch_live.end()) return hipErrorInvalidValue;
+  ScratchBlock blk = it->second;
+  g_scratch_live.erase(it);
+  blk.stream = s;  // kernels of this call may still be running: reusable in stream order only
+  g_scratch_free.push_back(blk);
+  return hipSuccess;
+}
 
 static int upload(mmh_ctx *ctx, const void *src, size_t bytes, void **dst) {
   MMH_HIP(hipMalloc(dst, bytes));
@@ -238,6 +315,15 @@ extern "C" int mmh_ctx_info(const mmh_ctx *ctx, size_t *N, size_t *L, uint64_t *
   }
   if (t) *t = ctx->t;
   if (gamma) *gamma = ctx->gamma;
+  return MMH_OK;
+}
+
+extern "C" int mmh_scratch_release(void) {
+  MMH_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  int device = 0;
+  MMH_HIP(hipGetDevice(&device));
+  scratch_drop_free(device);
   return MMH_OK;
 }
 

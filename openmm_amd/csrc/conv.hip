@@ -293,7 +293,7 @@ static int pointwise_mac(const mmh_conv_plan *p, const u64 *image_ntt, const u64
   void *wp = nullptr, *wl = nullptr, *flag = nullptr, *U = nullptr;
   int rc = MMH_OK;
   auto grab = [&](void **b, size_t bytes) {
-    if (!rc && hipMallocAsync(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+    if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
   grab(&wp, (size_t)C * Mpad * 4);
   grab(&wl, (size_t)C * Mpad * 16);
@@ -319,7 +319,7 @@ static int pointwise_mac(const mmh_conv_plan *p, const u64 *image_ntt, const u64
     if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
   }
   for (void *b : {wp, wl, flag, U})
-    if (b) (void)hipFreeAsync(b, s);
+    if (b) (void)scratch_free(b, s);
   if (rc) set_error("pointwise_mac: launch or allocation failed");
   return rc;
 }
@@ -513,10 +513,10 @@ extern "C" int mmh_conv_encrypt_image(const mmh_conv_plan *p, const uint64_t *d_
   MMH_REQUIRE(p && d_sk_ntt && d_img && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (p->n_in << p->ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (p->n_in << p->ctx->logN) * 8, s));
   int rc = mmh_conv_encode_image(p, d_img, (u64 *)pts, stream);
   if (!rc) rc = mmh_encrypt_symmetric(p->ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, p->n_in, d_cts, stream);
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }
 
@@ -541,10 +541,10 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   int rc = MMH_OK;
   auto cleanup = [&]() {
     for (void *b : {image, acc, zero, f_ntt, mask_t})
-      if (b) (void)hipFreeAsync(b, s);
+      if (b) (void)scratch_free(b, s);
   };
   auto grab = [&](void **b, size_t bytes) {
-    if (!rc && hipMallocAsync(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+    if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
   grab(&image, p->n_in * 4 * N * 8);
   grab(&acc, p->n_out * 4 * N * 8);
@@ -630,11 +630,11 @@ extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt
   const mmh_ctx *ctx = p->ctx;
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (p->n_out << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (p->n_out << ctx->logN) * 8, s));
   int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, p->n_out, (u64 *)pts, stream);
   if (!rc)
     rc = launch_gather_targets(ctx, (const u64 *)pts, d_out, (size_t)p->meta.n_filters, p->n_targets, p->n_spatial,
                                (size_t)(p->out_h * p->out_w), p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }

@@ -189,10 +189,10 @@ extern "C" int mmh_fc_encrypt_input(const mmh_fc_plan *p, const uint64_t *d_sk_n
   MMH_REQUIRE(p && d_sk_ntt && d_vec && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (p->n_in << p->ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (p->n_in << p->ctx->logN) * 8, s));
   int rc = mmh_fc_encode_input(p, d_vec, (u64 *)pts, stream);
   if (!rc) rc = mmh_encrypt_symmetric(p->ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, p->n_in, d_cts, stream);
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }
 
@@ -213,12 +213,12 @@ static int fc_server_impl(const mmh_fc_plan *p, const uint64_t *d_in_cts, const 
   int rc = MMH_OK;
   const u64 *cts = d_in_cts;
   if (p->meta.is_shared_input) {  // :431-440
-    MMH_HIP(hipMallocAsync(&input, p->n_in * 4 * N * 8, s));
+    MMH_HIP(scratch_alloc(&input, p->n_in * 4 * N * 8, s));
     rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)input, stream);
     cts = (const u64 *)input;
   }
-  if (!rc && hipMallocAsync(&acc, p->n_out * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
-  if (!rc && hipMallocAsync(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && scratch_alloc(&acc, p->n_out * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && scratch_alloc(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   // :443-457: out[j] = sum_i input[i] * matrix[j][i]
   if (!rc)
     rc = mmh_mul_plain_acc(ctx, 0, cts, p->n_in, d_weight_pts, p->n_out * p->n_in, p->n_out, 1, p->n_in, 1, 0,
@@ -234,7 +234,7 @@ static int fc_server_impl(const mmh_fc_plan *p, const uint64_t *d_in_cts, const 
     rc = launch_share_from_mask(ctx, d_mask, d_out_share, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
                                 p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
   if (exact) {
-    if (!rc && hipMallocAsync(&mask_t, p->n_out * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+    if (!rc && scratch_alloc(&mask_t, p->n_out * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
     if (!rc) rc = mmh_reduce_mod_t(ctx, d_mask, (u64 *)mask_t, p->n_out * N, stream);
     if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)mask_t, p->n_out, 1, d_out_cts, stream);
     if (!rc)
@@ -243,10 +243,10 @@ static int fc_server_impl(const mmh_fc_plan *p, const uint64_t *d_in_cts, const 
   }
   // truncate_for_decryption :462-466 + removeUnusedCoeffs :525-561
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, p->n_out, stream);
-  if (input) (void)hipFreeAsync(input, s);
-  if (acc) (void)hipFreeAsync(acc, s);
-  if (zero) (void)hipFreeAsync(zero, s);
-  if (mask_t) (void)hipFreeAsync(mask_t, s);
+  if (input) (void)scratch_free(input, s);
+  if (acc) (void)scratch_free(acc, s);
+  if (zero) (void)scratch_free(zero, s);
+  if (mask_t) (void)scratch_free(mask_t, s);
   return rc;
 }
 
@@ -274,12 +274,12 @@ extern "C" int mmh_fc_decrypt(const mmh_fc_plan *p, const uint64_t *d_sk_ntt, co
   const mmh_ctx *ctx = p->ctx;
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (p->n_out << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (p->n_out << ctx->logN) * 8, s));
   int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, p->n_out, (u64 *)pts, stream);
   if (!rc)
     rc = launch_gather_targets(ctx, (const u64 *)pts, d_out, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
                                p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }
 
@@ -300,13 +300,13 @@ extern "C" int mmh_bn_encode_vector(const mmh_ctx *ctx, const uint64_t *d_vec, s
   MMH_REQUIRE(d_vec && d_pts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *slots = nullptr;
-  MMH_HIP(hipMallocAsync(&slots, (n_ct << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&slots, (n_ct << ctx->logN) * 8, s));
   int rc = MMH_OK;
   hipLaunchKernelGGL(chunk_pad_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, d_vec, (u64 *)slots, n_ct, n,
                      sub, ctx->logN);
   if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
   if (!rc) rc = mmh_batch_encode(ctx, (const u64 *)slots, n_ct, d_pts, stream);
-  (void)hipFreeAsync(slots, s);
+  (void)scratch_free(slots, s);
   return rc;
 }
 
@@ -317,10 +317,10 @@ extern "C" int mmh_bn_encrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
   MMH_REQUIRE(d_sk_ntt && d_vec && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (n_ct << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (n_ct << ctx->logN) * 8, s));
   int rc = mmh_bn_encode_vector(ctx, d_vec, n, (u64 *)pts, stream);
   if (!rc) rc = mmh_encrypt_symmetric(ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, n_ct, d_cts, stream);
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }
 
@@ -329,8 +329,8 @@ static int bn_tail(const mmh_ctx *ctx, const u64 *acc, size_t n, size_t n_ct, si
                    u64 *d_out_cts, u64 *d_out_share, hipStream_t s) {
   void *r = nullptr, *rpts = nullptr;
   int rc = mmh_mod_switch_to_last(ctx, acc, n_ct, d_out_cts, s);
-  if (!rc && hipMallocAsync(&r, n * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
-  if (!rc && hipMallocAsync(&rpts, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && scratch_alloc(&r, n * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && scratch_alloc(&rpts, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   if (!rc) {
     hipLaunchKernelGGL(bn_mask_kernel, dim3(nblk(n)), dim3(256), 0, s, d_random, (u64 *)r, d_out_share, n,
                        ctx->bfv.t);
@@ -339,8 +339,8 @@ static int bn_tail(const mmh_ctx *ctx, const u64 *acc, size_t n, size_t n_ct, si
   if (!rc) rc = mmh_bn_encode_vector(ctx, (const u64 *)r, n, (u64 *)rpts, s);
   if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)rpts, n_ct, 0, d_out_cts, s);
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, n_ct, nullptr, 1, s);
-  if (r) (void)hipFreeAsync(r, s);
-  if (rpts) (void)hipFreeAsync(rpts, s);
+  if (r) (void)scratch_free(r, s);
+  if (rpts) (void)scratch_free(rpts, s);
   (void)sub;
   return rc;
 }
@@ -358,16 +358,16 @@ extern "C" int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const
   int rc = MMH_OK;
   const u64 *cts = d_in_cts;
   if (d_share_pts) {  // hom_bn_ss.cc:263-265
-    MMH_HIP(hipMallocAsync(&sum, n_ct * 4 * N * 8, s));
+    MMH_HIP(scratch_alloc(&sum, n_ct * 4 * N * 8, s));
     rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, n_ct, 0, (u64 *)sum, stream);
     cts = (const u64 *)sum;
   }
-  if (!rc && hipMallocAsync(&acc, n_ct * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (!rc && scratch_alloc(&acc, n_ct * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   // :265-267: out[i] = cts[i] * scales[i]
   if (!rc) rc = mmh_mul_plain_acc(ctx, 0, cts, n_ct, d_scale_pts, n_ct, 1, n_ct, 1, 0, 1, 0, 0, 1, (u64 *)acc, stream);
   if (!rc) rc = bn_tail(ctx, (const u64 *)acc, n, n_ct, sub, d_random, d_out_cts, d_out_share, s);
-  if (sum) (void)hipFreeAsync(sum, s);
-  if (acc) (void)hipFreeAsync(acc, s);
+  if (sum) (void)scratch_free(sum, s);
+  if (acc) (void)scratch_free(acc, s);
   return rc;
 }
 
@@ -380,12 +380,12 @@ extern "C" int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, con
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
   void *acc = nullptr;
-  MMH_HIP(hipMallocAsync(&acc, n_ct * 4 * ctx->N * 8, s));
+  MMH_HIP(scratch_alloc(&acc, n_ct * 4 * ctx->N * 8, s));
   // hom_bn_ss.cc:304-306: out[i] = ex[i]*py[i] + ey[i]*px[i]; operands are [ex; ey] and [py; px]
   int rc = mmh_mul_plain_acc(ctx, 0, d_enc_xy, 2 * n_ct, d_pts_yx, 2 * n_ct, 1, n_ct, 2, n_ct, 1, 0, n_ct, 1,
                              (u64 *)acc, stream);
   if (!rc) rc = bn_tail(ctx, (const u64 *)acc, n, n_ct, sub, d_random, d_out_cts, d_out_share, s);
-  (void)hipFreeAsync(acc, s);
+  (void)scratch_free(acc, s);
   return rc;
 }
 
@@ -396,9 +396,9 @@ extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
   MMH_REQUIRE(d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr, *slots = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (n_ct << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (n_ct << ctx->logN) * 8, s));
   int rc = MMH_OK;
-  if (hipMallocAsync(&slots, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  if (scratch_alloc(&slots, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   if (!rc) rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, n_ct, (u64 *)pts, stream);  // hom_bn_ss.cc:389
   if (!rc) rc = mmh_batch_decode(ctx, (const u64 *)pts, n_ct, (u64 *)slots, stream);
   if (!rc) {
@@ -406,8 +406,8 @@ extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
                        ctx->logN);
     if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
   }
-  (void)hipFreeAsync(pts, s);
-  if (slots) (void)hipFreeAsync(slots, s);
+  (void)scratch_free(pts, s);
+  if (slots) (void)scratch_free(slots, s);
   return rc;
 }
 
@@ -518,10 +518,10 @@ extern "C" int mmh_bn_encrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_met
   MMH_REQUIRE(d_sk_ntt && d_tensor && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (g.n_ct << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (g.n_ct << ctx->logN) * 8, s));
   int rc = mmh_bn_encode_tensor(ctx, meta, d_tensor, (u64 *)pts, stream);
   if (!rc) rc = mmh_encrypt_symmetric(ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, g.n_ct, d_cts, stream);
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }
 
@@ -540,7 +540,7 @@ extern "C" int mmh_bn_direct_server(const mmh_ctx *ctx, const mmh_bn_tensor_meta
   void *acc = nullptr, *zero = nullptr, *zero_low = nullptr, *rnd = nullptr, *keep = nullptr;
   int rc = MMH_OK;
   auto grab = [&](void **b, size_t bytes) {
-    if (!rc && hipMallocAsync(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+    if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
   grab(&acc, n * 4 * N * 8);
   grab(&zero, n * 4 * N * 8);
@@ -573,7 +573,7 @@ extern "C" int mmh_bn_direct_server(const mmh_ctx *ctx, const mmh_bn_tensor_meta
   }
   if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, n, (const uint8_t *)keep, S, stream);
   for (void *b : {acc, zero, zero_low, rnd, keep})
-    if (b) (void)hipFreeAsync(b, s);
+    if (b) (void)scratch_free(b, s);
   return rc;
 }
 
@@ -584,7 +584,7 @@ extern "C" int mmh_bn_decrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_met
   MMH_REQUIRE(d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
-  MMH_HIP(hipMallocAsync(&pts, (g.n_ct << ctx->logN) * 8, s));
+  MMH_HIP(scratch_alloc(&pts, (g.n_ct << ctx->logN) * 8, s));
   int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, g.n_ct, (u64 *)pts, stream);
   if (!rc) {
     const size_t total = (size_t)(g.C * g.H * g.W);
@@ -592,6 +592,6 @@ extern "C" int mmh_bn_decrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_met
                        ctx->logN, g);
     if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
   }
-  (void)hipFreeAsync(pts, s);
+  (void)scratch_free(pts, s);
   return rc;
 }

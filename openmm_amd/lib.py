@@ -33,6 +33,7 @@ SIGNATURES = {
                      C.POINTER(_u64), C.POINTER(_u64)],
     "mmh_malloc": [C.POINTER(_vp), _sz],
     "mmh_free": [_vp],
+    "mmh_scratch_release": [],
     "mmh_memcpy_h2d": [_vp, _vp, _sz, _vp],
     "mmh_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "mmh_memset": [_vp, _int, _sz, _vp],
