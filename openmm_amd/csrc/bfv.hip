@@ -631,12 +631,13 @@ extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t
 
 // addRandomMask + truncate_for_decryption + removeUnusedCoeffs of the shipped USE_APPROX_RESHARE build
 // (hom_conv2d_ss.cc:761-788, :698-703, :800-851; hom_fc_ss.cc:473-561) on n accumulated ciphertexts:
-// d_acc [n][2][2][N] in NTT form at the first level (consumed), d_out [n][2][N] at the last level.
+// d_acc [n][2][2][N] at the first level, in NTT or coefficient form (consumed), d_out [n][2][N] at the last.
 // Six launches: inverse NTT of acc, forward NTT of u straight from the signed samples, pk product,
 // inverse NTT, and one pass that mod-switches, adds the encryption of zero and e1, subtracts the mask,
 // truncates and clears the unused coefficients.  Same bits as the step-by-step entry points.
 namespace mmh {
-int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
+int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
+                        const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
                         u64 *d_out, hipStream_t s) {
   if (n == 0) return MMH_OK;
@@ -645,7 +646,7 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, size_t n, const u64 *d_p
   StreamBuf u(s), zero(s);
   MMH_HIP(u.alloc(n * N * 8));
   MMH_HIP(zero.alloc(n * 2 * N * 8));
-  CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
+  if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
   CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
   LAUNCH(mul_pk_kernel, n * N, s, u.as<u64>(), d_pk_ntt_last, zero.as<u64>(), n * N, ctx->logN, 1, ctx->d_mods);
   CHECK_RC(ntt_dispatch(ctx, true, zero.as<u64>(), n * 2, 1, 0, s));

@@ -13,7 +13,7 @@ int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys,
                  int mod_base, hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
-int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
+int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
                         u64 *d_out, hipStream_t s);
 int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
@@ -26,6 +26,7 @@ struct ImgWindow {
   int nc, nh, nw;          // window size before mocking
   int lo_y, hi_y, lo_x, hi_x;
 };
+struct PwChannel { int row, e; };  // 1x1 route: channel -> input ciphertext row (channel slice) and rotation
 }  // namespace mmh
 
 struct mmh_conv_plan {
@@ -48,7 +49,7 @@ struct mmh_conv_plan {
   // 1x1 filters with few channels per polynomial: multiply-accumulate as a mod-q matrix product over
   // channels (pointwise_mac below) instead of transforming M*Cs sparse filter polynomials
   bool pointwise = false;
-  uint64_t *d_monomial_ntt = nullptr;    // [win_c][2][N]: NTT of X^(origin - c*plane); null when it is all ones
+  mmh::PwChannel *d_pw_chan = nullptr;   // [C rounded up to 32]: input row (channel slice) and rotation of a channel
   std::vector<void *> allocs;
 };
 
@@ -140,28 +141,31 @@ int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t g
 // ------------------------------------------------------------------ 1x1 filters, few channels per polynomial
 // EncodeFilter gives a 1x1 filter polynomial one monomial per channel of its slice:
 //   f[m][s] = sum_c w[m][s*wc + c] X^(origin - c*plane),
-// so  sum_s ct[s] * f[m][s]  =  sum_ch w[m][ch] * (ct[s(ch)] * X^(origin - c(ch)*plane))  over all channels.
-// In NTT form the bracket is U[ch] = NTT(ct[s(ch)]) (.) NTT(X^e) with a per-plan table of wc monomial
-// transforms, and the layer becomes the mod-q matrix product W[M x C] * U[C x columns] with scalar
-// weights: no filter polynomial is transformed or streamed (M*Cs*64 KiB in the dyadic form).  Everything is
-// exact mod q_l, so the result equals the per-term multiply_plain schedule bit for bit.  Cheaper than the
-// transform route while wc is small (C*4 instructions against Cs*(2 NTTs + MAC) per output column).
+// so  sum_s ct[s] * f[m][s]  =  sum_ch w[m][ch] * (X^e(ch) * ct[s(ch)])  over all channels, and X^e * ct is
+// the ciphertext rotated by e coefficients with the wrapped ones negated (X^N = -1).  The layer is then the
+// mod-q matrix product W[M x C] * U[C x columns] with scalar weights on the coefficient form: no filter
+// polynomial is built, transformed or streamed (M*Cs*64 KiB in the dyadic form), the input needs no
+// forward and the result no inverse transform, and of c0 only the coefficients that survive
+// removeUnusedCoeffs are computed (c1 keeps all N: hom_conv2d_ss.cc:828 walks ct.data(0) only).
+// Everything is exact mod q_l, so the kept coefficients equal the per-term multiply_plain schedule bit
+// for bit.  Cheaper than the transform route while wc is small (per output column C scalar MACs against
+// Cs * (2 NTTs + 4 dyadic MACs)); measured break-even near 28 channels per polynomial.
 constexpr int kPwMaxWc = 24;  // measured break-even near 28 channels per polynomial
 constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as w + 2^20
 
-// weights [M][C] (mod t) -> biased 32-bit form wp[C][Mpad], lifted 64-bit form wl[2][C][Mpad], and a flag
+// weights [M][C] (mod t) -> biased 32-bit form wp[Cpad][Mpad], lifted 64-bit form wl[2][Cpad][Mpad], and a flag
 // that is raised when some weight does not fit the fast form.  STRIDED: read them back from encoded
 // filter plaintexts instead of the raw tensor.
 template <bool FROM_PTS>
 __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__ src, u32 *__restrict__ wp,
                                                          u64 *__restrict__ wl, u32 *__restrict__ flag, int M,
-                                                         int Mpad, int C, int wc, int n_cslices, int logN,
+                                                         int Mpad, int C, int Cpad, int wc, int n_cslices, int logN,
                                                          long origin, long plane, ModC t, u64 thr, u64 q0, u64 q1) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)C * Mpad) return;
+  if (idx >= (size_t)Cpad * Mpad) return;
   const int m = (int)(idx % Mpad), ch = (int)(idx / Mpad);
-  u64 v = 0;
-  if (m < M) {
+  u64 v = 0;  // filters and channels beyond the real ones weigh nothing
+  if (m < M && ch < C) {
     if (FROM_PTS) {
       const int sl = ch / wc, c = ch % wc;
       v = src[(((size_t)m * n_cslices + sl) << logN) + (origin - c * plane)];
@@ -174,25 +178,11 @@ __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__
   if (mag >= (u64(1) << kPwBiasLog)) atomicOr(flag, 1u);
   wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
   wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
-  wl[(size_t)C * Mpad + idx] = neg ? v + (q1 - t.q) : v;         // limb 1
-}
-
-// U[ch][sp][p][l][i] = image[s(ch)*S + sp][p][l][i] * mono[c(ch)][l][i] mod q_l
-__global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ image, const u64 *__restrict__ mono,
-                                                        u64 *__restrict__ U, size_t total, int logN, size_t S, int wc,
-                                                        const DevMod *__restrict__ mods) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const size_t N = size_t(1) << logN, i = idx & (N - 1);
-  const int l = (int)((idx >> logN) & 1), pl = (int)((idx >> logN) & 3);
-  const size_t row = idx >> (logN + 2), sp = row % S, ch = row / S;
-  const size_t sl = ch / wc, c = ch % wc;
-  const u64 x = image[(((sl * S + sp) * 4 + pl) << logN) + i];
-  U[idx] = mul_mod(x, mono[((c * 2 + l) << logN) + i], mods[l]);
+  wl[(size_t)Cpad * Mpad + idx] = neg ? v + (q1 - t.q) : v;      // limb 1
 }
 
 // Two filters against both halves of one column value: four independent v_mad_u64_u32 in one asm
-// statement (hipcc pads every statement boundary), weights from SGPRs.
+// statement (hipcc pads every statement boundary).
 __device__ __forceinline__ void mad_pair(u32 s_w0, u32 s_w1, u32 a0, u32 a1, u64 &x00, u64 &x01, u64 &x10,
                                          u64 &x11) {
   u64 carry;
@@ -201,81 +191,135 @@ __device__ __forceinline__ void mad_pair(u32 s_w0, u32 s_w1, u32 a0, u32 a1, u64
       "v_mad_u64_u32 %2, %4, %6, %7, %2\n\t"
       "v_mad_u64_u32 %3, %4, %6, %8, %3"
       : "+v"(x00), "+v"(x01), "+v"(x10), "+v"(x11), "=&s"(carry)
-      : "s"(s_w0), "s"(s_w1), "v"(a0), "v"(a1));
+      : "v"(s_w0), "v"(s_w1), "v"(a0), "v"(a1));
 }
-struct alignas(64) PwWeights16 { u32 v[16]; };
+template <int TM>
+struct alignas(4 * TM) PwWeights { u32 v[TM]; };
 
-// acc[m][col] = sum_ch W[m][ch] * U[ch][col] mod q_l.  One lane per column, 16 filters per wave, the four
-// waves of a workgroup share the column tile (their loads of U hit the same cache lines) and take
-// different filters, so the weights of a wave are uniform and come in through scalar loads.
+// acc[m*S + sp][p][l][i] = sum_ch W[m][ch] * (X^e(ch) * image[s(ch)*S + sp])[p][l][i] mod q_l.
+// A workgroup owns a tile of 64 columns (sp, p, l, i..i+63) and 64 filters: its 256 threads stage the
+// column values (rotation and sign applied once) and the 64 x 16 weights of 16 channels at a time in LDS,
+// with the loads of the next chunk in flight during the products of this one; every wave then
+// multiplies the staged columns into its own 16 filters, reading their weights as LDS broadcasts.
+// Tiles of c0 without a kept coefficient write zeros and leave.
 // Fast form: u = a0 + a1*2^30, acc0 += w'*a0, acc1 += w'*a1 with w' = w + 2^20 < 2^21: every sum of
 // <= 4096 terms stays below 2^63, one v_mad_u64_u32 each and no carries; the bias is removed at the end
 // with the column sums B0, B1:  sum w*u = (acc0 + acc1*2^30) - 2^20*(B0 + B1*2^30).
-__global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ U, const u32 *__restrict__ wp,
+constexpr int kPwChunk = 16;  // channels staged per step
+
+// Two instantiations are launched back to back; the device-side flag tells each whether it is the one to
+// run (the general form needs 172 VGPRs, which would halve the occupancy of the fast form).
+// TM filters per wave (4*TM per workgroup): 16 when that still fills the chip, else 8.
+template <bool FAST, int TM>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ image, const u32 *__restrict__ wp,
                                                       const u64 *__restrict__ wl, const u32 *__restrict__ flag,
-                                                      u64 *__restrict__ acc, int M, int Mpad, int C, size_t cols,
-                                                      int logN, const DevMod *__restrict__ mods) {
-  constexpr int TM = 16;
+                                                      const uint8_t *__restrict__ keep,
+                                                      const PwChannel *__restrict__ chan, u64 *__restrict__ acc, int M,
+                                                      int Mpad, int Cpad, size_t S, int logN,
+                                                      const DevMod *__restrict__ mods) {
+  constexpr int PER = kPwChunk / 4, TF = 4 * TM;  // channels per wave per staging step, filters per workgroup
+  if ((*flag == 0) != FAST) return;
+  constexpr bool fast = FAST;
+  __shared__ u64 tile[2][kPwChunk][64];
+  __shared__ __align__(16) u32 wtile[2][kPwChunk][TF];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const size_t col = (size_t)blockIdx.x * 64 + lane;
-  const int l = (int)((((size_t)blockIdx.x * 64) >> logN) & 1);
-  const int mbase = blockIdx.y * 64 + wave * TM;
-  if (mbase >= M) return;
-  const DevMod q = mods[l];
-  const u64 *__restrict__ up = U + col;
+  const int N = 1 << logN;
+  const size_t col = (size_t)blockIdx.x * 64 + lane, cols = S * 4 * N;
+  const int i = (int)(col & (N - 1));
+  const int pl = (int)((((size_t)blockIdx.x * 64) >> logN) & 3), l = pl & 1;   // uniform over the tile
+  const size_t sp = ((size_t)blockIdx.x * 64) >> (logN + 2);
+  const int mbase = blockIdx.y * TF + wave * TM;
   u64 res[TM];
-  if (*flag == 0) {
-    // weights of channel ch for this wave's 16 filters: one 64-byte scalar load, fetched one channel ahead
-    const PwWeights16 *__restrict__ w = reinterpret_cast<const PwWeights16 *>(wp + mbase);
-    const size_t wstep = (size_t)Mpad / TM;
-    u64 a0s[TM], a1s[TM], B0 = 0, B1 = 0;
+  const bool live = pl >= 2 || __ballot(keep[(sp << logN) + i] != 0) != 0;
+  if (!live) {
 #pragma unroll
-    for (int j = 0; j < TM; ++j) a0s[j] = a1s[j] = 0;
-    u64 un = up[0];
-    PwWeights16 wn = w[0];
-    for (int ch = 0; ch < C; ++ch) {
-      const u64 u = un;
-      const PwWeights16 wc = wn;
-      if (ch + 1 < C) {
-        un = up[(size_t)(ch + 1) * cols];
-        wn = w[(size_t)(ch + 1) * wstep];
-      }
-      const u32 a0 = (u32)u & 0x3fffffffu, a1 = (u32)(u >> 30);
-      B0 += a0, B1 += a1;
-#pragma unroll
-      for (int j = 0; j < TM; j += 2) mad_pair(wc.v[j], wc.v[j + 1], a0, a1, a0s[j], a1s[j], a0s[j + 1], a1s[j + 1]);
-    }
-    // bias term 2^20*(B0 + B1*2^30) mod q
-    const u64 blo = B0 + (B1 << 30), bhi = (B1 >> 34) + (blo < B0);
-    const u64 bias = reduce128_wide((bhi << kPwBiasLog) | (blo >> (64 - kPwBiasLog)), blo << kPwBiasLog, q);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const u64 lo = a0s[j] + (a1s[j] << 30), hi = (a1s[j] >> 34) + (lo < a0s[j]);
-      res[j] = sub_mod(reduce128_wide(hi, lo, q), bias, q.q);
-    }
+    for (int j = 0; j < TM; ++j) res[j] = 0;
   } else {
-    // general weights: lifted 64-bit values, lazy 128-bit sums reduced every 8 terms (8 q^2 < q 2^64)
-    const u64 *__restrict__ w = wl + (size_t)l * C * Mpad + mbase;
-    u64 lo[TM], hi[TM];
+    const DevMod q = mods[l];
+    const u64 *__restrict__ base = image + ((sp * 4 + pl) << logN);
+    const size_t row_step = S * 4 * N;
+    // this thread's share of a chunk: channels wave, wave + 4, ... of the chunk, column `lane`
+    u64 stage[PER];
+    int stage_e[PER];
+    uint4 stage_w;
+    const int wrow = threadIdx.x / TM, wcol = (threadIdx.x % TM) * 4;  // this thread's 4 staged weights
+    const bool stages_w = fast && wrow < kPwChunk;
+    auto issue = [&](int chunk) {
+      if (stages_w)
+        stage_w = *reinterpret_cast<const uint4 *>(wp + (size_t)(chunk * kPwChunk + wrow) * Mpad + blockIdx.y * TF + wcol);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) lo[j] = hi[j] = 0;
-    for (int ch = 0; ch < C; ++ch) {
-      const u64 u = up[(size_t)ch * cols];
-      const u64 *__restrict__ wr = w + (size_t)ch * Mpad;
+      for (int k = 0; k < PER; ++k) {
+        const PwChannel pc = chan[chunk * kPwChunk + k * 4 + wave];
+        stage_e[k] = pc.e;
+        stage[k] = base[(size_t)pc.row * row_step + ((i - pc.e) & (N - 1))];
+      }
+    };
+    auto commit = [&](int buf) {  // X^N = -1: coefficients that wrapped around come back negated
+      if (stages_w) *reinterpret_cast<uint4 *>(&wtile[buf][wrow][wcol]) = stage_w;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const u64 v = stage[k];
+        tile[buf][k * 4 + wave][lane] = i < stage_e[k] ? (v ? q.q - v : 0) : v;
+      }
+    };
+    const int n_chunks = Cpad / kPwChunk;
+    const u64 *__restrict__ wg = wl + (size_t)l * Cpad * Mpad + mbase;
+    u64 x0[TM], x1[TM], B0 = 0, B1 = 0;  // fast: the two 30-bit partial sums; general: 128-bit lo/hi
+#pragma unroll
+    for (int j = 0; j < TM; ++j) x0[j] = x1[j] = 0;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+      const int buf = chunk & 1;
+      if (chunk + 1 < n_chunks) issue(chunk + 1);
+      if (mbase < M) {
+        if (fast) {
+#pragma unroll 4
+          for (int k = 0; k < kPwChunk; ++k) {
+            const PwWeights<TM> wcur = *reinterpret_cast<const PwWeights<TM> *>(&wtile[buf][k][wave * TM]);
+            const u64 u = tile[buf][k][lane];
+            const u32 a0 = (u32)u & 0x3fffffffu, a1 = (u32)(u >> 30);
+            B0 += a0, B1 += a1;
+#pragma unroll
+            for (int j = 0; j < TM; j += 2)
+              mad_pair(wcur.v[j], wcur.v[j + 1], a0, a1, x0[j], x1[j], x0[j + 1], x1[j + 1]);
+          }
+        } else {
+          // general weights: lifted 64-bit values, lazy 128-bit sums reduced every 8 terms (8 q^2 < q 2^64)
+          for (int k = 0; k < kPwChunk; ++k) {
+            const u64 u = tile[buf][k][lane];
+            const u64 *__restrict__ wr = wg + (size_t)(chunk * kPwChunk + k) * Mpad;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              const u64 wj = wr[j], p = u * wj;
+              x0[j] += p;
+              x1[j] += mulhi64(u, wj) + (x0[j] < p);
+            }
+            if ((k & 7) == 7) {
+#pragma unroll
+              for (int j = 0; j < TM; ++j) x0[j] = reduce128_wide(x1[j], x0[j], q), x1[j] = 0;
+            }
+          }
+        }
+      }
+      if (chunk + 1 < n_chunks) commit(buf ^ 1);
+      __syncthreads();
+    }
+    if (fast) {
+      // bias term 2^20*(B0 + B1*2^30) mod q
+      const u64 blo = B0 + (B1 << 30), bhi = (B1 >> 34) + (blo < B0);
+      const u64 bias = reduce128_wide((bhi << kPwBiasLog) | (blo >> (64 - kPwBiasLog)), blo << kPwBiasLog, q);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        const u64 wj = wr[j], p = u * wj;
-        lo[j] += p;
-        hi[j] += mulhi64(u, wj) + (lo[j] < p);
+        const u64 lo = x0[j] + (x1[j] << 30), hi = (x1[j] >> 34) + (lo < x0[j]);
+        res[j] = sub_mod(reduce128_wide(hi, lo, q), bias, q.q);
       }
-      if ((ch & 7) == 7) {
+    } else {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) lo[j] = reduce128_wide(hi[j], lo[j], q), hi[j] = 0;
-      }
+      for (int j = 0; j < TM; ++j) res[j] = x0[j];  // reduced after the last group of 8
     }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) res[j] = reduce128_wide(hi[j], lo[j], q);
   }
 #pragma unroll
   for (int j = 0; j < TM; ++j)
@@ -284,41 +328,50 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ U,
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
-// acc[m*S + sp] (NTT form, [2][2][N] each) for all filters from the transformed image
-static int pointwise_mac(const mmh_conv_plan *p, const u64 *image_ntt, const u64 *d_filters_raw,
+// acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
+static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_filters_raw,
                          const u64 *d_filter_pts, u64 *acc, hipStream_t s) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const int M = (int)p->meta.n_filters, Mpad = (M + 63) / 64 * 64, C = (int)p->f.c, wc = (int)p->split.win_c;
-  void *wp = nullptr, *wl = nullptr, *flag = nullptr, *U = nullptr;
+  const int Cpad = (C + kPwChunk - 1) / kPwChunk * kPwChunk;
+  const long plane = p->split.win_h * p->split.win_w;
+  void *wp = nullptr, *wl = nullptr, *flag = nullptr;
   int rc = MMH_OK;
   auto grab = [&](void **b, size_t bytes) {
     if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
-  grab(&wp, (size_t)C * Mpad * 4);
-  grab(&wl, (size_t)C * Mpad * 16);
+  grab(&wp, (size_t)Cpad * Mpad * 4);
+  grab(&wl, (size_t)Cpad * Mpad * 16);
   grab(&flag, 4);
-  if (p->d_monomial_ntt) grab(&U, (size_t)C * cols * 8);
   if (!rc && hipMemsetAsync(flag, 0, 4, s) != hipSuccess) rc = MMH_ERR_INTERNAL;
   if (!rc) {
-    const long plane = p->split.win_h * p->split.win_w;
     if (d_filters_raw)
-      hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)C * Mpad)), dim3(256), 0, s, d_filters_raw,
-                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, wc, (int)p->n_cslices, ctx->logN,
+      hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)Cpad * Mpad)), dim3(256), 0, s, d_filters_raw,
+                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, Cpad, wc, (int)p->n_cslices, ctx->logN,
                          p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
     else
-      hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)C * Mpad)), dim3(256), 0, s, d_filter_pts,
-                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, wc, (int)p->n_cslices, ctx->logN,
+      hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)Cpad * Mpad)), dim3(256), 0, s, d_filter_pts,
+                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, Cpad, wc, (int)p->n_cslices, ctx->logN,
                          p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
-    if (U)
-      hipLaunchKernelGGL(pw_expand_kernel, dim3(nblk((size_t)C * cols)), dim3(256), 0, s, image_ntt,
-                         p->d_monomial_ntt, (u64 *)U, (size_t)C * cols, ctx->logN, S, wc, ctx->d_mods);
-    hipLaunchKernelGGL(pw_gemm_kernel, dim3((unsigned)(cols / 64), (unsigned)(Mpad / 64)), dim3(256), 0, s,
-                       U ? (const u64 *)U : image_ntt, (const u32 *)wp, (const u64 *)wl, (const u32 *)flag, acc, M,
-                       Mpad, C, cols, ctx->logN, ctx->d_mods);
+    // live column tiles: all of c1, of c0 only those with a kept coefficient (about n_targets / 64 per limb)
+    const size_t live_tiles = S * (2 * N / 64) + 2 * (p->n_targets / 64 + S);
+    const bool wide = live_tiles * (size_t)(Mpad / 64) >= 1024;   // 4 workgroups per CU with 16 filters per wave
+    auto launch = [&](auto kern, int tf) {
+      hipLaunchKernelGGL(kern, dim3((unsigned)(cols / 64), (unsigned)(Mpad / tf)), dim3(256), 0, s, image,
+                         (const u32 *)wp, (const u64 *)wl, (const u32 *)flag, p->d_keep, p->d_pw_chan, acc, M, Mpad,
+                         Cpad, S, ctx->logN, ctx->d_mods);
+    };
+    if (wide) {
+      launch(pw_gemm_kernel<true, 16>, 64);
+      launch(pw_gemm_kernel<false, 16>, 64);
+    } else {
+      launch(pw_gemm_kernel<true, 8>, 32);
+      launch(pw_gemm_kernel<false, 8>, 32);
+    }
     if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
   }
-  for (void *b : {wp, wl, flag, U})
+  for (void *b : {wp, wl, flag})
     if (b) (void)scratch_free(b, s);
   if (rc) set_error("pointwise_mac: launch or allocation failed");
   return rc;
@@ -448,16 +501,14 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
   const char *pw_env = getenv("MMH_CONV_POINTWISE");
   p->pointwise = f.h == 1 && f.w == 1 && sp.win_c <= kPwMaxWc && in.c <= 4096 && ctx->L == 2 &&
                  !(pw_env && pw_env[0] == '0');
-  if (p->pointwise && !(sp.win_c == 1 && p->filt_origin == 0)) {
-    std::vector<u64> mono((size_t)sp.win_c * 2 * N, 0);
-    for (long c = 0; c < sp.win_c; ++c)
-      for (int l = 0; l < 2; ++l) mono[((size_t)c * 2 + l) * N + (p->filt_origin - c * sp.win_h * sp.win_w)] = 1;
-    if ((rc = upload_vec(p, mono, &p->d_monomial_ntt)) ||
-        (rc = ntt_dispatch(ctx, false, p->d_monomial_ntt, (size_t)sp.win_c, 2, 0, nullptr))) {
+  if (p->pointwise) {
+    std::vector<PwChannel> chan((size_t)(in.c + kPwChunk - 1) / kPwChunk * kPwChunk, PwChannel{0, 0});
+    for (long ch = 0; ch < in.c; ++ch)
+      chan[ch] = PwChannel{(int)(ch / sp.win_c), (int)(p->filt_origin - (ch % sp.win_c) * sp.win_h * sp.win_w)};
+    if ((rc = upload_vec(p, chan, &p->d_pw_chan))) {
       mmh_conv_plan_destroy(p);
       return rc;
     }
-    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(MMH_ERR_INTERNAL, "monomial transform failed");
   }
   if ((rc = upload_vec(p, wins, &p->d_windows)) || (rc = upload_vec(p, coef, &p->d_tgt_coef)) ||
       (rc = upload_vec(p, dst, &p->d_tgt_dst)) || (rc = upload_vec(p, slice, &p->d_tgt_slice)) ||
@@ -554,7 +605,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && !p->meta.is_shared_input &&
       hipMemcpyAsync(image, d_in_cts, p->n_in * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
     rc = MMH_ERR_INTERNAL;
-  if (!rc) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
+  if (!rc && !p->pointwise) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   if (!rc && p->pointwise)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s);
@@ -569,7 +620,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && !exact) {
     // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
-    rc = reshare_tail_approx(ctx, (u64 *)acc, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S, d_out_cts, s);
+    rc = reshare_tail_approx(ctx, (u64 *)acc, !p->pointwise, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
+                             d_out_cts, s);
     if (!rc)
       rc = launch_share_from_mask(ctx, d_mask, d_out_share, M, p->n_targets, S, (size_t)(p->out_h * p->out_w),
                                   p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
@@ -579,7 +631,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     // by sub_plain and the share is the mask itself (:225-272, :358-380)
     grab(&zero, p->n_out * 2 * N * 8);
     grab(&mask_t, p->n_out * N * 8);
-    if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
+    if (!rc && !p->pointwise) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
     if (!rc) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
     if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
     if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
