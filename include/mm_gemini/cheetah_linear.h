@@ -64,6 +64,22 @@ class CheetahLinear {
   void bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor<uint64_t> &scale_vector, const BNMeta &meta,
                  Tensor<uint64_t> &out_tensor) const;
 
+  // Two-party self-check of conv2d (cheetah-api.cpp:206-296): BOB sends both of its shares, ALICE
+  // reconstructs input and output, recomputes the convolution in the clear (Tensor::Conv2D,
+  // tensor.h:274-362) and prints "HomConv: matches" / "HomConv: failed".  Like the reference it returns
+  // false only on a shape error; `mismatches`, when given, receives ALICE's count (the shipped
+  // USE_APPROX_RESHARE build may be off by one unit per element).
+  bool verify(const Tensor<uint64_t> &in_tensor_share, const std::vector<Tensor<uint64_t>> &filters,
+              const ConvMeta &meta, const Tensor<uint64_t> &out_tensor_share, int nbit_precision,
+              size_t *mismatches = nullptr) const;
+
+  template <typename T>
+  void safe_erase(T *mem, size_t cnt) const {  // cheetah-api.h:63-68
+    if (!mem || cnt == 0) return;
+    volatile unsigned char *p = reinterpret_cast<volatile unsigned char *>(mem);
+    for (size_t i = 0; i < sizeof(T) * cnt; ++i) p[i] = 0;
+  }
+
   uint64_t io_counter() const { return io_ ? io_->counter : 0; }
   int party() const { return party_; }
   uint64_t field_mod() const { return field_mod_; }

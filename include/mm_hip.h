@@ -269,6 +269,20 @@ int mmh_conv_server_weights(const mmh_conv_plan *plan, const uint64_t *d_in_cts,
                             const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                             uint64_t *d_out_share, void *stream);
+/* Static weights prepared once per model (the reference re-encodes the filters
+ * on every call, cheetah-api.cpp:418-423, which mmh_conv_server_weights reproduces).  The handle keeps
+ * what the layer call needs of the filters in device memory -- lifted NTT-form filter polynomials, or the
+ * scalar weight matrix for 1x1 layers -- so mmh_conv_server_prepared skips their encoding.  Results are
+ * bit-identical to mmh_conv_server_weights on the same filters.  The handle belongs to the plan it was
+ * made for; destroy it before the plan. */
+typedef struct mmh_conv_filters mmh_conv_filters;
+int mmh_conv_filters_prepare(const mmh_conv_plan *plan, const uint64_t *d_filters, mmh_conv_filters **out,
+                             void *stream);
+int mmh_conv_filters_destroy(mmh_conv_filters *filters);
+int mmh_conv_server_prepared(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                             const mmh_conv_filters *filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                             uint64_t *d_out_share, void *stream);
 /* HomConv2DSS::decryptToTensor (hom_conv2d_ss.cc:853-941): d_sk_ntt at the last level [1][N] */
 int mmh_conv_decrypt(const mmh_conv_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
                      uint64_t *d_out, void *stream);

@@ -53,6 +53,14 @@ struct mmh_conv_plan {
   std::vector<void *> allocs;
 };
 
+// filters of one layer as the server call consumes them (mmh_conv_filters_prepare)
+struct mmh_conv_filters {
+  const mmh_conv_plan *plan = nullptr;
+  uint64_t *f_ntt = nullptr;                 // transform route: [M*Cs][2][N] lifted, NTT form
+  uint32_t *wp = nullptr, *flag = nullptr;   // 1x1 route: biased weights, "needs the general form" flag
+  uint64_t *wl = nullptr;                    //            lifted 64-bit weights
+};
+
 namespace mmh {
 __device__ __forceinline__ u64 red_t(u64 v, const ModC &t) { return barrett128(0, v, t.q, t.barrett_hi, t.barrett_lo); }
 
@@ -328,52 +336,72 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
+struct PwSizes {
+  int M, Mpad, C, Cpad, wc;
+};
+static PwSizes pw_sizes(const mmh_conv_plan *p) {
+  PwSizes z;
+  z.M = (int)p->meta.n_filters, z.Mpad = (z.M + 63) / 64 * 64, z.C = (int)p->f.c, z.wc = (int)p->split.win_c;
+  z.Cpad = (z.C + kPwChunk - 1) / kPwChunk * kPwChunk;
+  return z;
+}
+// weights of the 1x1 route from the raw filters or from encoded plaintexts; flag must be zeroed first
+static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, const u64 *d_filter_pts, u32 *wp,
+                             u64 *wl, u32 *flag, hipStream_t s) {
+  const mmh_ctx *ctx = p->ctx;
+  const PwSizes z = pw_sizes(p);
+  const long plane = p->split.win_h * p->split.win_w;
+  MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
+  if (d_filters_raw)
+    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)z.Cpad * z.Mpad)), dim3(256), 0, s, d_filters_raw,
+                       wp, wl, flag, z.M, z.Mpad, z.C, z.Cpad, z.wc, (int)p->n_cslices, ctx->logN, p->filt_origin,
+                       plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+  else
+    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)z.Cpad * z.Mpad)), dim3(256), 0, s, d_filter_pts,
+                       wp, wl, flag, z.M, z.Mpad, z.C, z.Cpad, z.wc, (int)p->n_cslices, ctx->logN, p->filt_origin,
+                       plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
-static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_filters_raw,
-                         const u64 *d_filter_pts, u64 *acc, hipStream_t s) {
+static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const u32 *flag,
+                             u64 *acc, hipStream_t s) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
-  const int M = (int)p->meta.n_filters, Mpad = (M + 63) / 64 * 64, C = (int)p->f.c, wc = (int)p->split.win_c;
-  const int Cpad = (C + kPwChunk - 1) / kPwChunk * kPwChunk;
-  const long plane = p->split.win_h * p->split.win_w;
+  const PwSizes z = pw_sizes(p);
+  // live column tiles: all of c1, of c0 only those with a kept coefficient (about n_targets / 64 per limb)
+  const size_t live_tiles = S * (2 * N / 64) + 2 * (p->n_targets / 64 + S);
+  const bool wide = live_tiles * (size_t)(z.Mpad / 64) >= 1024;   // 4 workgroups per CU with 16 filters per wave
+  auto launch = [&](auto kern, int tf) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)(cols / 64), (unsigned)(z.Mpad / tf)), dim3(256), 0, s, image, wp, wl, flag,
+                       p->d_keep, p->d_pw_chan, acc, z.M, z.Mpad, z.Cpad, S, ctx->logN, ctx->d_mods);
+  };
+  if (wide) {
+    launch(pw_gemm_kernel<true, 16>, 64);
+    launch(pw_gemm_kernel<false, 16>, 64);
+  } else {
+    launch(pw_gemm_kernel<true, 8>, 32);
+    launch(pw_gemm_kernel<false, 8>, 32);
+  }
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_filters_raw,
+                         const u64 *d_filter_pts, u64 *acc, hipStream_t s) {
+  const PwSizes z = pw_sizes(p);
   void *wp = nullptr, *wl = nullptr, *flag = nullptr;
   int rc = MMH_OK;
   auto grab = [&](void **b, size_t bytes) {
     if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
-  grab(&wp, (size_t)Cpad * Mpad * 4);
-  grab(&wl, (size_t)Cpad * Mpad * 16);
+  grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
+  grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
   grab(&flag, 4);
-  if (!rc && hipMemsetAsync(flag, 0, 4, s) != hipSuccess) rc = MMH_ERR_INTERNAL;
-  if (!rc) {
-    if (d_filters_raw)
-      hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)Cpad * Mpad)), dim3(256), 0, s, d_filters_raw,
-                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, Cpad, wc, (int)p->n_cslices, ctx->logN,
-                         p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
-    else
-      hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)Cpad * Mpad)), dim3(256), 0, s, d_filter_pts,
-                         (u32 *)wp, (u64 *)wl, (u32 *)flag, M, Mpad, C, Cpad, wc, (int)p->n_cslices, ctx->logN,
-                         p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
-    // live column tiles: all of c1, of c0 only those with a kept coefficient (about n_targets / 64 per limb)
-    const size_t live_tiles = S * (2 * N / 64) + 2 * (p->n_targets / 64 + S);
-    const bool wide = live_tiles * (size_t)(Mpad / 64) >= 1024;   // 4 workgroups per CU with 16 filters per wave
-    auto launch = [&](auto kern, int tf) {
-      hipLaunchKernelGGL(kern, dim3((unsigned)(cols / 64), (unsigned)(Mpad / tf)), dim3(256), 0, s, image,
-                         (const u32 *)wp, (const u64 *)wl, (const u32 *)flag, p->d_keep, p->d_pw_chan, acc, M, Mpad,
-                         Cpad, S, ctx->logN, ctx->d_mods);
-    };
-    if (wide) {
-      launch(pw_gemm_kernel<true, 16>, 64);
-      launch(pw_gemm_kernel<false, 16>, 64);
-    } else {
-      launch(pw_gemm_kernel<true, 8>, 32);
-      launch(pw_gemm_kernel<false, 8>, 32);
-    }
-    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
-  }
+  if (rc) set_error("pointwise_mac: allocation failed");
+  if (!rc) rc = pointwise_weights(p, d_filters_raw, d_filter_pts, (u32 *)wp, (u64 *)wl, (u32 *)flag, s);
+  if (!rc) rc = pointwise_product(p, image, (const u32 *)wp, (const u64 *)wl, (const u32 *)flag, acc, s);
   for (void *b : {wp, wl, flag})
     if (b) (void)scratch_free(b, s);
-  if (rc) set_error("pointwise_mac: launch or allocation failed");
   return rc;
 }
 
@@ -577,10 +605,12 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                             const uint64_t *d_filter_pts, const uint64_t *d_filters_raw,
                             const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
                             const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream,
-                            const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr) {
+                            const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr,
+                            const mmh_conv_filters *prepared = nullptr) {
   const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
   MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
-  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw) && d_pk_ntt_last && d_u && d_e1 && d_mask &&
+  MMH_REQUIRE(!prepared || prepared->plan == p, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw || prepared) && d_pk_ntt_last && d_u && d_e1 && d_mask &&
                   d_out_cts && d_out_share,
               MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
@@ -599,7 +629,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   };
   grab(&image, p->n_in * 4 * N * 8);
   grab(&acc, p->n_out * 4 * N * 8);
-  if (!p->pointwise) grab(&f_ntt, M * Cs * 2 * N * 8);
+  if (!p->pointwise && !prepared) grab(&f_ntt, M * Cs * 2 * N * 8);
   // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
   if (!rc && p->meta.is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
   if (!rc && !p->meta.is_shared_input &&
@@ -607,16 +637,20 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     rc = MMH_ERR_INTERNAL;
   if (!rc && !p->pointwise) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
-  if (!rc && p->pointwise)
+  const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
+  if (!rc && p->pointwise && prepared)
+    rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->flag, (u64 *)acc, s);
+  if (!rc && p->pointwise && !prepared)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s);
-  if (!rc && !p->pointwise && d_filters_raw)
+  if (!rc && !p->pointwise && !prepared && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
                              p->split.win_w, 2, s);
-  if (!rc && !p->pointwise && !d_filters_raw) rc = ntt_lift_dispatch(ctx, d_filter_pts, (u64 *)f_ntt, M * Cs, 2, s);
+  if (!rc && !p->pointwise && !prepared && !d_filters_raw)
+    rc = ntt_lift_dispatch(ctx, d_filter_pts, (u64 *)f_ntt, M * Cs, 2, s);
   // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
   if (!rc && !p->pointwise)
-    rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, (const u64 *)f_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
+    rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, filt_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
   if (!rc && !exact) {
     // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
@@ -674,6 +708,59 @@ extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d
   MMH_REQUIRE(d_filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask,
                           d_out_cts, d_out_share, stream);
+}
+
+extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {
+  if (!f) return MMH_OK;
+  for (void *b : {(void *)f->f_ntt, (void *)f->wp, (void *)f->wl, (void *)f->flag})
+    if (b) (void)hipFree(b);
+  delete f;
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_filters_prepare(const mmh_conv_plan *p, const uint64_t *d_filters, mmh_conv_filters **out,
+                                        void *stream) {
+  MMH_REQUIRE(p && d_filters && out, MMH_ERR_NULL_POINTER);
+  *out = nullptr;
+  const mmh_ctx *ctx = p->ctx;
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  hipStream_t s = (hipStream_t)stream;
+  mmh_conv_filters *f = new mmh_conv_filters();
+  f->plan = p;
+  int rc = MMH_OK;
+  auto own = [&](void **b, size_t bytes) {
+    if (!rc && hipMalloc(b, bytes) != hipSuccess) rc = MMH_ERR_MEMORY;
+  };
+  if (p->pointwise) {
+    const PwSizes z = pw_sizes(p);
+    own((void **)&f->wp, (size_t)z.Cpad * z.Mpad * 4);
+    own((void **)&f->wl, (size_t)z.Cpad * z.Mpad * 16);
+    own((void **)&f->flag, 4);
+    if (!rc) rc = pointwise_weights(p, d_filters, nullptr, f->wp, f->wl, f->flag, s);
+  } else {
+    const size_t M = (size_t)p->meta.n_filters, Cs = p->n_cslices;
+    own((void **)&f->f_ntt, M * Cs * 2 * ctx->N * 8);
+    if (!rc)
+      rc = ntt_filter_dispatch(ctx, d_filters, f->f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w, (int)p->split.win_c,
+                               (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w, p->split.win_w, 2, s);
+  }
+  if (rc) {
+    if (rc == MMH_ERR_MEMORY) set_error("mmh_conv_filters_prepare: hipMalloc failed");
+    mmh_conv_filters_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_server_prepared(const mmh_conv_plan *p, const uint64_t *d_in_cts,
+                                        const uint64_t *d_share_pts, const mmh_conv_filters *filters,
+                                        const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
+                                        const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
+                                        void *stream) {
+  MMH_REQUIRE(filters, MMH_ERR_NULL_POINTER);
+  return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
+                          d_out_share, stream, nullptr, nullptr, filters);
 }
 
 extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,

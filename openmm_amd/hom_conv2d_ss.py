@@ -65,6 +65,25 @@ class Plan:
             pass
 
 
+class PreparedFilters:
+    """Static filters of one layer kept on the device in the form the server call consumes
+    (mmh_conv_filters).  Not in the reference, which re-encodes per call."""
+
+    def __init__(self, plan, filters, nonzero):
+        self.plan, self.nonzero = plan, nonzero
+        self.handle = L._vp()
+        L.check(plan.ctx.lib.mmh_conv_filters_prepare(plan.handle, L.dptr(filters.contiguous()),
+                                                      C.byref(self.handle), L._stream_ptr()))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.plan.ctx.lib.mmh_conv_filters_destroy(self.handle)
+                self.handle = L._vp()
+        except Exception:
+            pass
+
+
 class HomConv2DSS:
     def __init__(self):
         self.ctx = self.sk_ntt = self.pk_ntt = None
@@ -172,6 +191,32 @@ class HomConv2DSS:
                                                      L.dptr(e1), L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
                                                      L._stream_ptr()))
         self._need(bool(nz), 8, "conv2DOneFilter: filter with all zero is not supported")
+        return out_cts, out_share
+
+    # static weights: encode once per model, then conv2DSSPrepared per inference (same bits as
+    # conv2DSSFromWeights); the zero-filter rule of conv2DOneFilter :573-580 is settled here
+    def prepareFilters(self, filters, meta):
+        self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
+        self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
+        nz = bool((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
+        self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
+        return PreparedFilters(self.plan(meta), filters, nz)
+
+    def conv2DSSPrepared(self, img_share0, img_share1, prepared, meta, rand):
+        self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
+        p = self.plan(meta)
+        self._need(prepared.plan is p, 7, "conv2DSS: filters prepared for another layer")
+        self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
+        if meta.is_shared_input:
+            self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
+        u, e1, mask = rand
+        out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
+        out_share = self.ctx._empty(*p.out_shape)
+        L.check(self.ctx.lib.mmh_conv_server_prepared(p.handle, L.dptr(img_share0),
+                                                      L.dptr(img_share1 if meta.is_shared_input else None),
+                                                      prepared.handle, L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
+                                                      L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
+                                                      L._stream_ptr()))
         return out_cts, out_share
 
     # decryptToTensor (hom_conv2d_ss.cc:853-941)

@@ -3,6 +3,7 @@
 // conv2d :377-446, bn :527-603, BOLE :605-650.
 #include "mm_gemini/cheetah_linear.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -416,6 +417,72 @@ void CheetahLinear::BOLE(const Tensor<uint64_t> &x, const Tensor<uint64_t> &y, c
   // local cross term x_i * y_i on both sides (cheetah-api.cpp:648-649)
   must(mmh_bole_cross_term(out.p, dx.p, dy.p, n, field_mod_, nullptr), "BOLE cross term");
   out.download(out_vector.data(), n);
+}
+
+// cheetah-api.cpp:206-296.  Shares are combined mod base_mod; the cleartext convolution follows
+// Tensor::Conv2D (tensor.h:274-362): SAME pads (f - 1) in total with the larger half first.
+bool CheetahLinear::verify(const Tensor<uint64_t> &in_tensor_share, const std::vector<Tensor<uint64_t>> &filters,
+                           const ConvMeta &meta, const Tensor<uint64_t> &out_tensor_share, int nbit_precision,
+                           size_t *mismatches) const {
+  if (filters.empty()) {
+    fprintf(stderr, "CheetahLinear::verify number of filters = 0\n");
+    return false;
+  }
+  const TensorShape &ishape = in_tensor_share.shape(), &fshape = filters[0].shape();
+  const long stride = (long)meta.stride, H = ishape.height(), W = ishape.width(), fh = fshape.height(),
+             fw = fshape.width();
+  const long ph = meta.padding == Padding::SAME ? fh - 1 : 0, pw = meta.padding == Padding::SAME ? fw - 1 : 0;
+  if (stride < 1 || H + ph < fh || W + pw < fw) return false;
+  const TensorShape oshape({(int64_t)meta.n_filters, (H + ph - fh + stride) / stride, (W + pw - fw + stride) / stride});
+  if (!oshape.IsSameSize(out_tensor_share.shape())) {
+    fprintf(stderr, "CheetahLinear::verify oshape mismatch\n");
+    return false;
+  }
+  if (!ishape.IsSameSize(meta.ishape) || !fshape.IsSameSize(meta.fshape)) {
+    fprintf(stderr, "CheetahLinear::verify shape mismatch\n");
+    return false;
+  }
+  const size_t n_in = (size_t)ishape.num_elements(), n_out = (size_t)oshape.num_elements();
+  if (party_ == kBob) {
+    io_->send_data(in_tensor_share.data(), 8 * n_in);
+    io_->send_data(out_tensor_share.data(), 8 * n_out);
+    io_->flush();
+    return true;
+  }
+  std::vector<uint64_t> in(n_in), out(n_out);
+  io_->recv_data(in.data(), 8 * n_in);
+  io_->recv_data(out.data(), 8 * n_out);
+  const bool pow2 = (base_mod_ & (base_mod_ - 1)) == 0;
+  auto reduce = [&](uint64_t v) { return pow2 ? v & (base_mod_ - 1) : v % base_mod_; };
+  auto get_signed = [&](uint64_t v) { return v >= (base_mod_ + 1) / 2 ? (int64_t)(v - base_mod_) : (int64_t)v; };
+  double mn = 0, mx = 0;
+  for (size_t i = 0; i < n_in; ++i) {
+    in[i] = reduce(in[i] + in_tensor_share.data()[i]);
+    const double d = get_signed(in[i]) / std::pow(2., nbit_precision);
+    mn = i ? std::min(mn, d) : d, mx = i ? std::max(mx, d) : d;
+  }
+  printf("in_tensor values in [%g,%g]\n", mn, mx);
+  for (size_t i = 0; i < n_out; ++i) out[i] = reduce(out[i] + out_tensor_share.data()[i]);
+  const long padh = (ph + 1) / 2, padw = (pw + 1) / 2, OH = oshape.height(), OW = oshape.width(), C = ishape.channels();
+  size_t cnt_err = 0;
+  for (size_t m = 0; m < meta.n_filters; ++m)
+    for (long oh = 0, ih = -padh; oh < OH; ++oh, ih += stride)
+      for (long ow = 0, iw = -padw; ow < OW; ++ow, iw += stride) {
+        unsigned __int128 sum = 0;
+        for (long c = 0; c < C; ++c)
+          for (long r = 0; r < fh; ++r)
+            for (long q = 0; q < fw; ++q) {
+              const long y = ih + r, x = iw + q;
+              if (y < 0 || y >= H || x < 0 || x >= W) continue;  // zero padding
+              const unsigned __int128 prod = (unsigned __int128)reduce(filters[m](c, r, q)) * in[(c * H + y) * W + x];
+              sum += (uint64_t)(prod % base_mod_);
+            }
+        const uint64_t ground = (uint64_t)(sum % base_mod_);
+        if (get_signed(ground) != get_signed(out[(m * OH + oh) * OW + ow])) ++cnt_err;
+      }
+  printf(cnt_err == 0 ? "HomConv: matches\n" : "HomConv: failed\n");
+  if (mismatches) *mismatches = cnt_err;
+  return true;
 }
 
 }  // namespace gemini

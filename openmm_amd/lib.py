@@ -81,6 +81,9 @@ SIGNATURES = {
     "mmh_flood_add": [_vp, _vp, _vp, _sz, _vp],
     "mmh_reduce_mod_t": [_vp, _vp, _vp, _sz, _vp],
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_filters_prepare": [_vp, _vp, C.POINTER(_vp), _vp],
+    "mmh_conv_filters_destroy": [_vp],
+    "mmh_conv_server_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],
     "mmh_fc_plan_destroy": [_vp],

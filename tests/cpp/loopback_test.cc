@@ -200,6 +200,17 @@ int main(int argc, char **argv) {
           ok &= std::llabs(got - acc) <= 1;      // library_fixed_uniform_cheetah.cpp:199
         }
     EXPECT(ok, full ? "conv2d ResNet50 3x3 56x56x64->64: |err| <= 1" : "conv2d 6x14x14 3x3 SAME: |err| <= 1");
+    // CheetahLinear::verify (cheetah-api.cpp:206-296): exact comparison against the cleartext convolution;
+    // the approximate re-sharing of the shipped build leaves off-by-one elements, never a shape error
+    bool vok[2] = {false, false};
+    size_t bad_elems = 0;
+    both(A2, B2, [&](Party &p) {
+      vok[p.id - 1] = p.linear->verify(sh[p.id - 1], filters, meta, out[p.id - 1], 12, p.id == 1 ? &bad_elems : nullptr);
+    });
+    EXPECT(vok[0] && vok[1] && bad_elems <= (size_t)M * H * H, "verify runs on both parties and counts mismatches");
+    u64 secret[4] = {1, 2, 3, 4};
+    A2.linear->safe_erase(secret, 4);
+    EXPECT((secret[0] | secret[1] | secret[2] | secret[3]) == 0, "safe_erase zeroes the buffer");
 
     const int rows = full ? 1001 : 37, cols = full ? 2048 : 300;
     CheetahLinear::FCMeta fm{TensorShape({cols}), TensorShape({rows, cols}), true};

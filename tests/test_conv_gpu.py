@@ -116,6 +116,12 @@ def test_conv_layer_bit_exact(mm, ishape, fhw, M, same, stride, shared):
     one_out, one_share = server.conv2DSSFromWeights(got_cts, got_s, dev(filters), meta, (dev(u), dev(e1), dev(mask)))
     assert np.array_equal(host(one_out), ref_out)
     assert np.array_equal(host(one_share), ref_share)
+    # ... and so does the call on filters prepared once (static weights)
+    prep = server.prepareFilters(dev(filters), meta)
+    for _ in range(2):
+        pre_out, pre_share = server.conv2DSSPrepared(got_cts, got_s, prep, meta, (dev(u), dev(e1), dev(mask)))
+        assert np.array_equal(host(pre_out), ref_out)
+        assert np.array_equal(host(pre_share), ref_share)
     # the USE_APPROX_RESHARE=0 build of the same call: flood noise, e0 kept, mask mod t; exact identity
     flood, e0 = splitmix64(SEED + 60, cv.n_out * N).reshape(cv.n_out, N), noise(SEED + 61, (cv.n_out, N))
     words = splitmix64(SEED + 62, cv.n_out * N).reshape(cv.n_out, N)
