@@ -51,6 +51,30 @@ def cpu_baseline(seconds=12.0):
             "sample": f"{done} forward limb-NTTs N=4096 (oracle Harvey/Shoup C, OpenMP) in {dt:.1f}s"}
 
 
+def cpu_homconv_ms(reps=3):
+    """conv2DOneFilter loop of the ResNet50 3x3 56x56x64->64 layer on the host cores, in the reference's
+    own schedule (4096 multiply_plain + add_inplace, workers over filters like its ThreadPool;
+    hom_conv2d_ss.cc:563-619, :679-690) through the oracle port: the dominant part of what the GPU leg
+    `homconv_resnet50_3x3_56x56x64_ms` replaces (encoding and the re-sharing tail are not in this figure)."""
+    import numpy as np
+    from tests.oracle_binding import OracleCtx, A, uniform_mod, splitmix64
+    t, N, M, Cs = 1 << 37, 4096, 64, 64
+    o = OracleCtx(N, (60, 49), t)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    image = np.stack([np.stack([np.stack([uniform_mod(9 * k + 2 * j + l, N, q) for l, q in enumerate(o.q)])
+                                for j in range(2)]) for k in range(Cs)])
+    filters = np.zeros((M, Cs, N), dtype=np.uint64)
+    pos = (splitmix64(7, M * Cs * 9) % np.uint64(N)).reshape(M, Cs, 9).astype(np.int64)
+    val = (splitmix64(8, M * Cs * 9) % np.uint64(1 << 12)).reshape(M, Cs, 9) + np.uint64(1)
+    np.put_along_axis(filters, pos, val, axis=2)
+    out = np.zeros((M, 2, 2, N), dtype=np.uint64)
+    o.lib.mmo_conv_mac_reference(o.p, A(image), A(filters), M, Cs, 1, A(out), threads)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o.lib.mmo_conv_mac_reference(o.p, A(image), A(filters), M, Cs, 1, A(out), threads)
+    return (time.perf_counter() - t0) / reps * 1e3, threads
+
+
 def layer_legs(torch, openmm_amd, local):
     """Secondary legs of BASELINE.json's metric (configs[2]): server-side HomConv of the ResNet50
     3x3 56x56x64->64 layer and BOLE on 2^20 elements, ms per layer, inputs resident in HBM."""
@@ -298,6 +322,10 @@ def main():
         }
         if world == 1 and not args.no_cpu and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline()
+            ms, threads = cpu_homconv_ms()
+            extra["homconv_resnet50_3x3_cpu_port_ms"] = ms
+            extra["homconv_resnet50_3x3_cpu_port_note"] = (
+                f"conv2DOneFilter loop only, reference schedule (4096 multiply_plain), oracle port on {threads} host threads")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
