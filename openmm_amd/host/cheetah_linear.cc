@@ -6,7 +6,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <array>
 #include <map>
+#include <mutex>
 
 #include "mm_hip.h"
 
@@ -79,9 +81,35 @@ struct CheetahLinear::Impl {
   mutable uint64_t stream_id = 1;
   mm::IOChannel *io = nullptr;
 
+  // layer geometry is computed once per shape (the reference redoes it on every call)
+  mutable std::mutex plan_mu;
+  mutable std::map<std::array<int64_t, 9>, mmh_conv_plan *> conv_plans;
+  mutable std::map<std::array<int64_t, 3>, mmh_fc_plan *> fc_plans;
+
   ~Impl() {
+    for (auto &kv : conv_plans) mmh_conv_plan_destroy(kv.second);
+    for (auto &kv : fc_plans) mmh_fc_plan_destroy(kv.second);
     mmh_ctx_destroy(ring.ctx);
     mmh_ctx_destroy(field.ctx);
+  }
+  mmh_conv_plan *conv_plan(const mmh_conv_meta &m) const {
+    const std::array<int64_t, 9> key{m.in_c, m.in_h, m.in_w, m.f_h, m.f_w, m.n_filters, m.padding_same, m.stride,
+                                     m.is_shared_input};
+    std::lock_guard<std::mutex> g(plan_mu);
+    auto it = conv_plans.find(key);
+    if (it != conv_plans.end()) return it->second;
+    mmh_conv_plan *plan = nullptr;
+    must(mmh_conv_plan_create(ring.ctx, &m, &plan), "CheetahLinear::conv2d shape inference");
+    return conv_plans[key] = plan;
+  }
+  mmh_fc_plan *fc_plan(const mmh_fc_meta &m) const {
+    const std::array<int64_t, 3> key{m.rows, m.cols, m.is_shared_input};
+    std::lock_guard<std::mutex> g(plan_mu);
+    auto it = fc_plans.find(key);
+    if (it != fc_plans.end()) return it->second;
+    mmh_fc_plan *plan = nullptr;
+    must(mmh_fc_plan_create(ring.ctx, &m, &plan), "CheetahLinear::fc getSplit");
+    return fc_plans[key] = plan;
   }
   uint64_t sid() const { return stream_id++; }
 
@@ -196,9 +224,7 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
   mmh_conv_meta m{meta.ishape.channels(), meta.ishape.height(), meta.ishape.width(), meta.fshape.height(),
                   meta.fshape.width(), (int64_t)meta.n_filters, meta.padding == Padding::SAME, (int32_t)meta.stride,
                   meta.is_shared_input};
-  mmh_conv_plan *plan = nullptr;
-  must(mmh_conv_plan_create(I.ring.ctx, &m, &plan), "CheetahLinear::conv2d shape inference");
-  struct Guard { mmh_conv_plan *p; ~Guard() { mmh_conv_plan_destroy(p); } } guard{plan};
+  mmh_conv_plan *plan = I.conv_plan(m);
   size_t n_in, n_cs, n_sp, n_out;
   int64_t oshape[3];
   must(mmh_conv_plan_info(plan, &n_in, &n_cs, &n_sp, &n_out, oshape, nullptr), "plan_info");
@@ -253,9 +279,7 @@ void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64
   const Impl &I = *impl_;
   const size_t N = Impl::N, L = Impl::L;
   mmh_fc_meta m{meta.weight_shape.rows(), meta.weight_shape.cols(), meta.is_shared_input};
-  mmh_fc_plan *plan = nullptr;
-  must(mmh_fc_plan_create(I.ring.ctx, &m, &plan), "CheetahLinear::fc getSplit");
-  struct Guard { mmh_fc_plan *p; ~Guard() { mmh_fc_plan_destroy(p); } } guard{plan};
+  mmh_fc_plan *plan = I.fc_plan(m);
   size_t n_in, n_out;
   must(mmh_fc_plan_info(plan, nullptr, &n_in, &n_out), "plan_info");
   const size_t rows = (size_t)m.rows, cols = (size_t)m.cols;

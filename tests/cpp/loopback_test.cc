@@ -3,6 +3,7 @@
 // process (two threads) over LoopbackIO and an ideal COT, draw random inputs, run the protocol,
 // reconstruct and compare with cleartext arithmetic.
 //   usage: loopback_test [log2(n) for the vector tests, default 16] [full=0|1: ResNet50 3x3 layer]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -184,6 +185,14 @@ int main(int argc, char **argv) {
       }
     Tensor<u64> out[2];
     both(A2, B2, [&](Party &p) { p.linear->conv2d(sh[p.id - 1], filters, meta, out[p.id - 1]); });
+    {  // host buffers in, host buffers out, both parties and the byte pipe in this process: the
+       // PCIe- and transport-inclusive time of one layer, second call (plan cached)
+      const auto t0 = std::chrono::steady_clock::now();
+      both(A2, B2, [&](Party &p) { p.linear->conv2d(sh[p.id - 1], filters, meta, out[p.id - 1]); });
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      printf("[time] conv2d %dx%dx%d 3x3 -> %d, host tensors to host tensors, two parties in-process: %.2f ms\n", C, H,
+             H, M, ms);
+    }
     bool ok = out[0].shape().IsSameSize(TensorShape({M, H, H}));
     for (int m_ = 0; m_ < M && ok; ++m_)
       for (int oh = 0; oh < H; ++oh)
