@@ -201,14 +201,27 @@ __device__ __forceinline__ void mad_pair(u32 s_w0, u32 s_w1, u32 a0, u32 a1, u64
       : "+v"(x00), "+v"(x01), "+v"(x10), "+v"(x11), "=&s"(carry)
       : "v"(s_w0), "v"(s_w1), "v"(a0), "v"(a1));
 }
+// the same with the two weights in SGPRs (wave-uniform)
+__device__ __forceinline__ void mad_pair_s(u32 s_w0, u32 s_w1, u32 a0, u32 a1, u64 &x00, u64 &x01, u64 &x10,
+                                           u64 &x11) {
+  u64 carry;
+  asm("v_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+      "v_mad_u64_u32 %1, %4, %5, %8, %1\n\t"
+      "v_mad_u64_u32 %2, %4, %6, %7, %2\n\t"
+      "v_mad_u64_u32 %3, %4, %6, %8, %3"
+      : "+v"(x00), "+v"(x01), "+v"(x10), "+v"(x11), "=&s"(carry)
+      : "s"(s_w0), "s"(s_w1), "v"(a0), "v"(a1));
+}
 template <int TM>
 struct alignas(4 * TM) PwWeights { u32 v[TM]; };
 
 // acc[m*S + sp][p][l][i] = sum_ch W[m][ch] * (X^e(ch) * image[s(ch)*S + sp])[p][l][i] mod q_l.
 // A workgroup owns a tile of 64 columns (sp, p, l, i..i+63) and 64 filters: its 256 threads stage the
-// column values (rotation and sign applied once) and the 64 x 16 weights of 16 channels at a time in LDS,
-// with the loads of the next chunk in flight during the products of this one; every wave then
-// multiplies the staged columns into its own 16 filters, reading their weights as LDS broadcasts.
+// column values of 16 channels at a time in LDS (rotation and sign applied once, the loads of the next
+// chunk in flight during the products of this one); every wave then multiplies the staged columns into
+// its own 16 filters, whose weights are wave-uniform and arrive through scalar loads in bursts of four
+// channels.  (Weights read as LDS broadcasts cost 1 KiB of LDS bandwidth per ds_read_b128 and made the
+// loop LDS-bound: 36 LDS cycles against 32 VALU cycles per channel and wave.)
 // Tiles of c0 without a kept coefficient write zeros and leave.
 // Fast form: u = a0 + a1*2^30, acc0 += w'*a0, acc1 += w'*a1 with w' = w + 2^20 < 2^21: every sum of
 // <= 4096 terms stays below 2^63, one v_mad_u64_u32 each and no carries; the bias is removed at the end
@@ -229,7 +242,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
   if ((*flag == 0) != FAST) return;
   constexpr bool fast = FAST;
   __shared__ u64 tile[2][kPwChunk][64];
-  __shared__ __align__(16) u32 wtile[2][kPwChunk][TF];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int N = 1 << logN;
@@ -250,12 +262,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
     // this thread's share of a chunk: channels wave, wave + 4, ... of the chunk, column `lane`
     u64 stage[PER];
     int stage_e[PER];
-    uint4 stage_w;
-    const int wrow = threadIdx.x / TM, wcol = (threadIdx.x % TM) * 4;  // this thread's 4 staged weights
-    const bool stages_w = fast && wrow < kPwChunk;
     auto issue = [&](int chunk) {
-      if (stages_w)
-        stage_w = *reinterpret_cast<const uint4 *>(wp + (size_t)(chunk * kPwChunk + wrow) * Mpad + blockIdx.y * TF + wcol);
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
         const PwChannel pc = chan[chunk * kPwChunk + k * 4 + wave];
@@ -264,7 +271,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
       }
     };
     auto commit = [&](int buf) {  // X^N = -1: coefficients that wrapped around come back negated
-      if (stages_w) *reinterpret_cast<uint4 *>(&wtile[buf][wrow][wcol]) = stage_w;
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
         const u64 v = stage[k];
@@ -284,15 +290,24 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
       if (chunk + 1 < n_chunks) issue(chunk + 1);
       if (mbase < M) {
         if (fast) {
-#pragma unroll 4
-          for (int k = 0; k < kPwChunk; ++k) {
-            const PwWeights<TM> wcur = *reinterpret_cast<const PwWeights<TM> *>(&wtile[buf][k][wave * TM]);
-            const u64 u = tile[buf][k][lane];
-            const u32 a0 = (u32)u & 0x3fffffffu, a1 = (u32)(u >> 30);
-            B0 += a0, B1 += a1;
+          // weights of 4 channels at a time for this wave's filters: scalar loads issued as one burst
+          // (scalar returns are unordered, so a wait drains them all: one wait per 4 channels)
+          const PwWeights<TM> *__restrict__ wrow =
+              reinterpret_cast<const PwWeights<TM> *>(wp + (size_t)chunk * kPwChunk * Mpad + mbase);
+          const size_t wstep = (size_t)Mpad / TM;
+          for (int k0 = 0; k0 < kPwChunk; k0 += 4) {
+            PwWeights<TM> w4[4];
 #pragma unroll
-            for (int j = 0; j < TM; j += 2)
-              mad_pair(wcur.v[j], wcur.v[j + 1], a0, a1, x0[j], x1[j], x0[j + 1], x1[j + 1]);
+            for (int j4 = 0; j4 < 4; ++j4) w4[j4] = wrow[(size_t)(k0 + j4) * wstep];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+              const u64 u = tile[buf][k0 + j4][lane];
+              const u32 a0 = (u32)u & 0x3fffffffu, a1 = (u32)(u >> 30);
+              B0 += a0, B1 += a1;
+#pragma unroll
+              for (int j = 0; j < TM; j += 2)
+                mad_pair_s(w4[j4].v[j], w4[j4].v[j + 1], a0, a1, x0[j], x1[j], x0[j + 1], x1[j + 1]);
+            }
           }
         } else {
           // general weights: lifted 64-bit values, lazy 128-bit sums reduced every 8 terms (8 q^2 < q 2^64)
