@@ -18,8 +18,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_NTT = {4096: 65536, 8192: 131072}   # 2*N*8 B per limb-NTT
 BUTTERFLIES = {4096: 24576, 8192: 53248}       # (N/2) log2 N
-MADS_PER_BUTTERFLY = 9     # 64-bit Shoup multiply = 9 v_mad_u64_u32 (ntt kernel)
-MAD_PEAK = 34.5e12         # v_mad_u64_u32 lanes/s measured on MI355X (profiles/r01_a_valu_probe.txt)
+# Irreducible full-rate VALU operations per butterfly: 9 v_mad_u64_u32 for the 64-bit Shoup product of the
+# 60-bit limb, 8 FP64 operations (5-op exact modular product + 3 adds) for the 49-bit limb;
+# the batch is half and half.  Both instruction kinds issue at the same measured rate.
+MADS_PER_BUTTERFLY = (9 + 8) / 2
+MAD_PEAK = 34.5e12         # lanes/s measured on MI355X (profiles/r01_a_valu_probe.txt, r01_f64_probe.txt)
 
 
 def pmc_traffic(ntts_per_launch):
@@ -315,7 +318,7 @@ def main():
                          "kernel": "ntt_fwd_kernel<12>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ntts_per_step * BYTES_PER_NTT[4096],
                          "int64_valu": {"achieved": ntts_per_step * BUTTERFLIES[4096] * MADS_PER_BUTTERFLY
-                                        / launch_s / 1e12, "peak": MAD_PEAK / 1e12, "unit": "T v_mad_u64_u32/s",
+                                        / launch_s / 1e12, "peak": MAD_PEAK / 1e12, "unit": "T full-rate VALU ops/s (v_mad_u64_u32 | FP64)",
                                         "frac": ntts_per_step * BUTTERFLIES[4096] * MADS_PER_BUTTERFLY
                                         / launch_s / MAD_PEAK}},
             "extra": extra,
