@@ -107,6 +107,12 @@ class HomConv2DSS:
         if not cond:
             raise L.MMHError(code, what)
 
+    def _check_rand(self, p, rand, names):
+        """every sampled polynomial batch is [n_out, N]: the kernels index them with the plan's sizes"""
+        self._need(len(rand) == len(names), 7, "conv2DSS: rand = (" + ", ".join(names) + ")")
+        for r, name in zip(rand, names):
+            self._need(r is not None and tuple(r.shape) == (p.n_out, self.ctx.N), 3, f"conv2DSS: {name} shape")
+
     # encryptImage (hom_conv2d_ss.cc:497-522); rand = (a [n_in,L,N] uniform, e [n_in,N] signed)
     def encryptImage(self, img, meta, rand):
         self._need(self.ctx is not None and self.sk_ntt is not None, 1, "encryptImage: no secret key")
@@ -145,7 +151,7 @@ class HomConv2DSS:
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         p = self.plan(meta)
         self._need(filters.shape[0] == meta.n_filters, 3, "conv2DSS: #filters")
-        self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
+        self._need(tuple(img_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 3, "conv2DSS: #ciphertexts")
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
         # conv2DOneFilter :573-580: a filter whose polynomials are all zero is an error
@@ -155,6 +161,9 @@ class HomConv2DSS:
             nz = L.DeferredFlag((filters.reshape(meta.n_filters, -1) != 0).any(dim=1).all())
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)
+        self._check_rand(p, rand, ("flood", "u", "e0", "e1", "mask") if exact else ("u", "e1", "mask"))
+        if meta.is_shared_input:
+            self._need(tuple(img_share1.shape) == (p.n_in, self.ctx.N), 3, "conv2DSS: share plaintexts shape")
         if exact:
             flood, u, e0, e1, mask = rand
             L.check(self.ctx.lib.mmh_conv_server_exact(p.handle, L.dptr(img_share0),
@@ -178,10 +187,13 @@ class HomConv2DSS:
         self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
         self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
         p = self.plan(meta)
-        self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
+        self._need(tuple(img_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 3, "conv2DSS: #ciphertexts")
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
         nz = L.DeferredFlag((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
+        self._check_rand(p, rand, ("u", "e1", "mask"))
+        if meta.is_shared_input:
+            self._need(tuple(img_share1.shape) == (p.n_in, self.ctx.N), 3, "conv2DSS: share plaintexts shape")
         u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)
@@ -206,9 +218,12 @@ class HomConv2DSS:
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         p = self.plan(meta)
         self._need(prepared.plan is p, 7, "conv2DSS: filters prepared for another layer")
-        self._need(img_share0.shape[0] == p.n_in, 3, "conv2DSS: #ciphertexts")
+        self._need(tuple(img_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 3, "conv2DSS: #ciphertexts")
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
+        self._check_rand(p, rand, ("u", "e1", "mask"))
+        if meta.is_shared_input:
+            self._need(tuple(img_share1.shape) == (p.n_in, self.ctx.N), 3, "conv2DSS: share plaintexts shape")
         u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)

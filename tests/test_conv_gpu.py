@@ -224,7 +224,8 @@ def test_sharded_conv_single_rank_equals_unsharded(mm):
         srv = HomConv2DSS()
         srv.setUp(g, pk_ntt=pk)
         plan = srv.plan(meta)
-        cts, share1 = smp.uniform(plan.n_in), torch.randint(0, T, (4, 10, 10), dtype=torch.int64, device="cuda")
+        cts = smp.uniform(2 * plan.n_in).view(plan.n_in, 2, 2, N)
+        share1 = torch.randint(0, T, (4, 10, 10), dtype=torch.int64, device="cuda")
         filters = torch.randint(1, 1 << 12, (5, 4, 3, 3), dtype=torch.int64, device="cuda")
         rand = (smp.ternary(plan.n_out), smp.noise(plan.n_out), smp.uniform(plan.n_out, lv=1)[:, 0].contiguous())
         s1 = srv.encodeImage(share1, meta)
@@ -233,3 +234,40 @@ def test_sharded_conv_single_rank_equals_unsharded(mm):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     finally:
         dist.destroy_process_group()
+
+
+def test_layer_calls_on_two_streams_share_the_scratch_cache(mm):
+    """layer calls are re-entrant: scratch blocks are cached per stream, so calls enqueued on two streams
+    must not hand each other's live buffers around; results equal the single-stream ones"""
+    import torch
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    g = mm.Context(N, (60, 49), T)
+    smp = mm.Sampler(g, key=bytes(range(32)))
+    _, pk = smp.keygen()
+    srv = HomConv2DSS()
+    srv.setUp(g, pk_ntt=pk)
+    metas = [Meta((16, 14, 14), (16, 3, 3), 8, 1, 1, True), Meta((12, 28, 28), (12, 1, 1), 6, 0, 1, True)]
+    jobs = []
+    for k, meta in enumerate(metas):
+        plan = srv.plan(meta)
+        gen = torch.Generator(device="cuda").manual_seed(SEED + k)
+        cts = smp.uniform(2 * plan.n_in).view(plan.n_in, 2, 2, N)
+        share = torch.randint(0, T, meta.ishape, dtype=torch.int64, device="cuda", generator=gen)
+        filters = torch.randint(1, 1 << 12, (meta.n_filters,) + meta.fshape, dtype=torch.int64, device="cuda",
+                                generator=gen)
+        rand = (smp.ternary(plan.n_out), smp.noise(plan.n_out), smp.uniform(plan.n_out, lv=1)[:, 0].contiguous())
+        jobs.append((meta, cts, share, filters, rand))
+    run = lambda j: srv.conv2DSSFromWeights(j[1], srv.encodeImage(j[2], j[0]), j[3], j[0], j[4])
+    ref = [run(j) for j in jobs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [None, None]
+    for rep in range(3):
+        for k, j in enumerate(jobs):
+            streams[k].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[k]):
+                got[k] = run(j)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1])
+    assert g.lib.mmh_scratch_release() == 0
