@@ -78,6 +78,36 @@ def cpu_homconv_ms(reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, threads
 
 
+def conversion_leg(torch, openmm_amd):
+    """ring_to_field local share arithmetic on 10^7 elements (tests/ring_to_field_test.cpp:171), l=32,
+    p=4293918721, ALICE's side: the pre kernel (in -> tmp, msb, corr) and the post kernel (tmp, msb, y -> out)
+    around the host COT, device-resident; 25 algorithmic bytes per element each."""
+    import openmm_amd.lib as L
+    lib = L.load_library()
+    n, l, p = 10_000_000, 32, 4293918721
+    gen = torch.Generator(device="cuda").manual_seed(0x4D264D)
+    x = torch.randint(0, 1 << l, (n,), dtype=torch.int64, device="cuda", generator=gen)
+    y = torch.randint(0, p, (n,), dtype=torch.int64, device="cuda", generator=gen)
+    tmp, corr, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    msb = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s = L._stream_ptr()
+
+    def both():
+        L.check(lib.mmh_r2f_pre(1, L.dptr(x), n, l, p, L.dptr(tmp), L.dptr(msb), L.dptr(corr), s))
+        L.check(lib.mmh_r2f_post(1, L.dptr(tmp), L.dptr(msb), L.dptr(y), n, l, p, L.dptr(out), s))
+
+    both()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        both()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    return {"ring_to_field_1e7_pre_post_us": us, "ring_to_field_hbm_frac": 50.0 * n / (us * 1e-6) / HBM_PEAK}
+
+
 def layer_legs(torch, openmm_amd, local):
     """Secondary legs of BASELINE.json's metric (configs[2]): server-side HomConv of the ResNet50
     3x3 56x56x64->64 layer and BOLE on 2^20 elements, ms per layer, inputs resident in HBM."""
@@ -297,6 +327,7 @@ def main():
         del d8, c8
         if world == 1:
             extra.update(layer_legs(torch, openmm_amd, local))
+            extra.update(conversion_leg(torch, openmm_amd))
 
     if not args.headline_only:
         net = resnet50_leg(torch, dist, openmm_amd, local, world, rank)

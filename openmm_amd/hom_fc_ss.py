@@ -93,14 +93,18 @@ class HomFCSS:
     def matVecMul(self, matrix, vec_share0, vec_share1, meta, rand, exact=False):
         self._need(self.pk_ntt is not None, 1, "matVecMul: no public key")
         p = self.plan(meta)
-        self._need(vec_share0.shape[0] == p.n_in, 7, "matVecMul: #input ciphertexts")
+        self._need(tuple(vec_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 7, "matVecMul: #input ciphertexts")
+        self._need(len(rand) == (5 if exact else 3), 7, "matVecMul: rand")
+        for r in rand:  # every sampled polynomial batch is [n_out, N]
+            self._need(r is not None and tuple(r.shape) == (p.n_out, self.ctx.N), 3, "matVecMul: rand shape")
+        self._need(tuple(matrix.shape) == (p.n_out, p.n_in, self.ctx.N), 7, "matVecMul: weight plaintexts shape")
         self._need(tuple(matrix.shape[:2]) == (p.n_out, p.n_in), 7, "matVecMul: #weight blocks")
         # :414-422: a sub-matrix that encodes to zero is rejected
         nz = getattr(matrix, "_mm_nonzero", None)
         if nz is None:
             nz = L.DeferredFlag((matrix != 0).any(dim=2).all())
         if meta.is_shared_input:
-            self._need(vec_share1 is not None and vec_share1.shape[0] == p.n_in, 3, "matVecMul: #shares")
+            self._need(vec_share1 is not None and tuple(vec_share1.shape) == (p.n_in, self.ctx.N), 3, "matVecMul: #shares")
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(meta.weight_shape[0])
         if exact:
