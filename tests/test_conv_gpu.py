@@ -26,6 +26,9 @@ CASES = [
     ((12, 28, 28), (1, 1), 4, 0, 1, True),     # five channels per polynomial, ragged last slice (5 + 5 + 2)
     ((2, 70, 70), (1, 1), 2, 0, 1, False),     # spatial windows as well
     ((7, 56, 56), (1, 1), 70, 0, 2, True),     # stride trick (28x28 after subsampling), more than 64 filters
+    ((40, 14, 14), (1, 1), 3, 0, 1, True),     # 20 channels per polynomial, 40 channels = three staging chunks
+    ((1, 4, 4), (1, 1), 1, 0, 1, True),        # smallest layer: one channel, one filter, one ciphertext
+    ((1, 5, 5), (3, 3), 1, 1, 1, False),       # smallest 3x3 layer
 ]
 
 
