@@ -269,6 +269,10 @@ int mmh_conv_server_weights(const mmh_conv_plan *plan, const uint64_t *d_in_cts,
                             const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                             uint64_t *d_out_share, void *stream);
+/* The conv2DOneFilter :573-580 rule on the raw filters [M][C][fh][fw]: *d_flag (device word) becomes 1
+ * when some filter is all zero mod t, else 0.  Asynchronous, so a caller can read the verdict back after
+ * it has enqueued the layer. */
+int mmh_conv_check_filters(const mmh_conv_plan *plan, const uint64_t *d_filters, uint32_t *d_flag, void *stream);
 /* Static weights prepared once per model (the reference re-encodes the filters
  * on every call, cheetah-api.cpp:418-423, which mmh_conv_server_weights reproduces).  The handle keeps
  * what the layer call needs of the filters in device memory -- lifted NTT-form filter polynomials, or the

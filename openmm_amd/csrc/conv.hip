@@ -100,6 +100,16 @@ __global__ __launch_bounds__(256) void encode_filter_kernel(const u64 *__restric
   polys[((m * n_cslices + slice) << logN) + coef] = red_t(filt[idx], t);
 }
 
+// conv2DOneFilter :573-580 rejects a filter whose polynomials are all zero, i.e. whose weights are all
+// 0 mod t: one workgroup per filter raises *flag when it finds such a filter
+__global__ __launch_bounds__(256) void zero_filter_kernel(const u64 *__restrict__ filt, size_t per_filter, ModC t,
+                                                          u32 *__restrict__ flag) {
+  const u64 *__restrict__ f = filt + (size_t)blockIdx.x * per_filter;
+  int nz = 0;
+  for (size_t i = threadIdx.x; i < per_filter; i += 256) nz |= red_t(f[i], t) != 0;
+  if (!__syncthreads_or(nz) && threadIdx.x == 0) atomicOr(flag, 1u);
+}
+
 // share tensor from the RNS mask: out[m][dst] = scale_and_round(r[m*S + slice][coef])
 __global__ __launch_bounds__(256) void share_from_mask_kernel(const u64 *__restrict__ r, u64 *__restrict__ out,
                                                               size_t n_filters, size_t n_targets, size_t n_spatial,
@@ -598,6 +608,17 @@ extern "C" int mmh_conv_encode_filters(const mmh_conv_plan *p, const uint64_t *d
   hipLaunchKernelGGL(encode_filter_kernel, dim3(nblk(total)), dim3(256), 0, s, d_filters, d_pts, total, ctx->logN,
                      (int)p->f.c, (int)p->f.h, (int)p->f.w, (int)p->split.win_c, (int)p->n_cslices, p->filt_origin,
                      p->split.win_h * p->split.win_w, p->split.win_w, ctx->bfv.t);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_check_filters(const mmh_conv_plan *p, const uint64_t *d_filters, uint32_t *d_flag,
+                                      void *stream) {
+  MMH_REQUIRE(p && d_filters && d_flag, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  MMH_HIP(hipMemsetAsync(d_flag, 0, 4, s));
+  hipLaunchKernelGGL(zero_filter_kernel, dim3((unsigned)p->meta.n_filters), dim3(256), 0, s, d_filters,
+                     (size_t)p->f.count(), p->ctx->bfv.t, d_flag);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }

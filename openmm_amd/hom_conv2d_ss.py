@@ -14,6 +14,11 @@ from . import lib as L
 VALID, SAME = 0, 1  # gemini::Padding (tensor_shape.h:11)
 
 
+def torch_empty_flag(like):
+    import torch
+    return torch.empty(1, dtype=torch.int32, device=like.device)
+
+
 def _mod_t(x, t):
     """int64 tensor holding uint64 bits, reduced mod t (power of two: mask; else torch remainder on
     the non-negative representatives the callers pass)"""
@@ -190,7 +195,10 @@ class HomConv2DSS:
         self._need(tuple(img_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 3, "conv2DSS: #ciphertexts")
         if meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
-        nz = L.DeferredFlag((_mod_t(filters, self.ctx.t) != 0).reshape(meta.n_filters, -1).any(dim=1).all())
+        filters = filters.contiguous()
+        bad = torch_empty_flag(filters)
+        L.check(self.ctx.lib.mmh_conv_check_filters(p.handle, L.dptr(filters), L.dptr(bad), L._stream_ptr()))
+        nz = L.DeferredFlag(bad, negate=True)   # true when no filter is all zero
         self._check_rand(p, rand, ("u", "e1", "mask"))
         if meta.is_shared_input:
             self._need(tuple(img_share1.shape) == (p.n_in, self.ctx.N), 3, "conv2DSS: share plaintexts shape")

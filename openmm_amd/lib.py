@@ -81,6 +81,7 @@ SIGNATURES = {
     "mmh_flood_add": [_vp, _vp, _vp, _sz, _vp],
     "mmh_reduce_mod_t": [_vp, _vp, _vp, _sz, _vp],
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_check_filters": [_vp, _vp, _vp, _vp],
     "mmh_conv_filters_prepare": [_vp, _vp, C.POINTER(_vp), _vp],
     "mmh_conv_filters_destroy": [_vp],
     "mmh_conv_server_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -146,16 +147,17 @@ class DeferredFlag:
     then waits for that early copy (not for the kernels behind it).  The reference decides the same
     conditions on host data before it starts (hom_conv2d_ss.cc:573-580, hom_fc_ss.cc:414-422)."""
 
-    def __init__(self, flag_dev):
+    def __init__(self, flag_dev, negate=False):
         import torch
-        self.host = torch.empty((), dtype=torch.bool, pin_memory=True)
-        self.host.copy_(flag_dev, non_blocking=True)
+        self.negate = negate
+        self.host = torch.empty((), dtype=flag_dev.dtype, pin_memory=True)
+        self.host.copy_(flag_dev.reshape(()), non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
     def __bool__(self):
         self.event.synchronize()
-        return bool(self.host)
+        return bool(self.host) != self.negate
 
 
 def dptr(t):
