@@ -175,7 +175,32 @@ RESNET50_CONVS = [
 ]
 
 
-def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5):
+# SqueezeNet (BASELINE.json configs[3]; networks/main_sqnet.cpp:3107-3764): 26 convolutions, no FC.
+SQUEEZENET_CONVS = [
+    (3, 227, 227, 3, 3, 64, 0, 2, 1), (64, 56, 56, 1, 1, 16, 0, 1, 1), (16, 56, 56, 1, 1, 64, 0, 1, 2),
+    (16, 56, 56, 3, 3, 64, 1, 1, 2), (128, 56, 56, 1, 1, 16, 0, 1, 1), (128, 27, 27, 1, 1, 32, 0, 1, 1),
+    (32, 27, 27, 1, 1, 128, 0, 1, 2), (32, 27, 27, 3, 3, 128, 1, 1, 2), (256, 27, 27, 1, 1, 32, 0, 1, 1),
+    (256, 13, 13, 1, 1, 48, 0, 1, 1), (48, 13, 13, 1, 1, 192, 0, 1, 2), (48, 13, 13, 3, 3, 192, 1, 1, 2),
+    (384, 13, 13, 1, 1, 48, 0, 1, 1), (384, 13, 13, 1, 1, 64, 0, 1, 1), (64, 13, 13, 1, 1, 256, 0, 1, 2),
+    (64, 13, 13, 3, 3, 256, 1, 1, 2), (512, 13, 13, 1, 1, 64, 0, 1, 1), (512, 13, 13, 1, 1, 1000, 0, 1, 1),
+]
+
+
+def densenet121_convs():
+    """DenseNet121 (BASELINE.json configs[4]; networks/main_densenet121.cpp, 121 Conv2DWrapper / FusedBN calls):
+    stem, four dense blocks of (1x1 C -> 128, 3x3 128 -> 32) pairs with C growing by 32, three 1x1
+    transitions and the 1x1 classifier on the pooled 1x1 image."""
+    convs = [(3, 224, 224, 7, 7, 64, 1, 2, 1)]
+    for hw, c0, layers, trans in ((56, 64, 6, 128), (28, 128, 12, 256), (14, 256, 24, 512), (7, 512, 16, None)):
+        convs += [(c0 + 32 * k, hw, hw, 1, 1, 128, 0, 1, 1) for k in range(layers)]
+        convs.append((128, hw, hw, 3, 3, 32, 1, 1, layers))
+        if trans:
+            convs.append((c0 + 32 * layers, hw, hw, 1, 1, trans, 0, 1, 1))
+    convs.append((1024, 1, 1, 1, 1, 1000, 0, 1, 1))
+    return convs
+
+
+def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None, prefix="resnet50", with_fc=True):
     """Second half of BASELINE.json's metric: server-side HE compute of all 53 ResNet50 conv layers
     + FC 2048->1001 (what CheetahLinear::conv2d / ::fc run between receiving the client's
     ciphertexts and sending the result, cheetah-api.cpp:417-445, :520-548): filter encoding and
@@ -212,7 +237,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5):
     srv = HomConv2DSS()
     srv.setUp(ctx, pk_ntt=pk)
     per_layer, total, cached_total = [], 0.0, 0.0
-    for (c, h, w, fh, fw, m, same, stride, count) in RESNET50_CONVS:
+    for (c, h, w, fh, fw, m, same, stride, count) in (convs or RESNET50_CONVS):
         shared = c != 3  # first conv runs with kIsSharedInput=false (main_resnet50.cpp:4979)
         meta = Meta((c, h, w), (c, fh, fw), m, same, stride, shared)
         sh = ShardedConv(srv, meta) if world > 1 else None
@@ -238,6 +263,12 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5):
                 cts, srv.encodeImage(share, meta) if shared else None, prep, meta, rand))
             del prep
         del cts, share, filters, rand
+    if not with_fc:
+        out = {f"{prefix}_he_linear_ms": total, f"{prefix}_conv_layers": sum(x[-1] for x in convs),
+               f"{prefix}_conv_ms_per_shape": per_layer}
+        if world == 1:
+            out[f"{prefix}_he_linear_prepared_filters_ms"] = cached_total
+        return out
     fc = HomFCSS()
     fc.setUp(ctx, pk_ntt=pk)
     fmeta = FcMeta((1001, 2048), (2048,), True)
@@ -331,8 +362,15 @@ def main():
 
     if not args.headline_only:
         net = resnet50_leg(torch, dist, openmm_amd, local, world, rank)
+        sq = resnet50_leg(torch, dist, openmm_amd, local, world, rank, convs=SQUEEZENET_CONVS, prefix="squeezenet",
+                          with_fc=False)
+        dn = resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=3, convs=densenet121_convs(),
+                          prefix="densenet121", with_fc=False)
+        dn.pop("densenet121_conv_ms_per_shape")
         if rank == 0:
             extra.update(net)
+            extra.update(sq)
+            extra.update(dn)
     if rank == 0:
         line = {
             "metric": "64-bit NTTs/sec (N=4096/8192) + ResNet50 HE-linear ms at 1/2/4/8 GPUs",
