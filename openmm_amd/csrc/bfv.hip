@@ -26,6 +26,30 @@ struct StreamBuf {
   T *as() { return reinterpret_cast<T *>(p); }
 };
 
+// out = in (+|-) scaled plaintext, out-of-place: every coefficient of both polynomials is written, so
+// no separate copy of the ciphertexts is needed
+__global__ __launch_bounds__(256) void add_plain_copy_kernel(const u64 *__restrict__ in, const u64 *__restrict__ pts,
+                                                             u64 *__restrict__ out, size_t total, int logN, int sub,
+                                                             BfvConsts b, int lv, const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const LevelConsts &c = b.lv[lv];
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const u64 m = pts[idx];
+  const u64 fix = m ? scale_fix(m, b, c) : 0;
+  for (int l = 0; l < c.limbs; ++l) {
+    const DevMod &q = mods[l];
+    const size_t o0 = (((k * 2) * c.limbs + l) << logN) + i, o1 = (((k * 2 + 1) * c.limbs + l) << logN) + i;
+    u64 v = in[o0];
+    if (m) {
+      const u64 sc = scaled_plain(m, fix, c.delta_mod_q[l], q);
+      v = sub ? sub_mod(v, sc, q.q) : add_mod(v, sc, q.q);
+    }
+    out[o0] = v;
+    out[o1] = in[o1];
+  }
+}
+
 __global__ __launch_bounds__(256) void add_plain_kernel(u64 *__restrict__ cts, const u64 *__restrict__ pts,
                                                         size_t total, int logN, int sub, BfvConsts b, int lv,
                                                         const DevMod *__restrict__ mods) {
@@ -324,11 +348,20 @@ __global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restri
                                                              const u64 *__restrict__ mask, u64 *__restrict__ out,
                                                              size_t total, int logN, u64 inv_qlast, u64 mask0,
                                                              u64 mask1, const uint8_t *__restrict__ keep,
-                                                             size_t keep_period, const DevMod *__restrict__ mods) {
+                                                             size_t keep_period, const DevMod *__restrict__ mods,
+                                                             const int *__restrict__ share_dst, size_t share_plane,
+                                                             u64 *__restrict__ share_out, BfvConsts b) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
   if (idx >= total) return;
   const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
   const DevMod &q0 = mods[0];
+  if (share_dst) {  // the other party's share: scale-and-round of the mask at the target coefficients
+    const int dst = share_dst[((k % keep_period) << logN) + i];
+    if (dst >= 0) {
+      const u64 x[2] = {mask[idx], 0};
+      share_out[(k / keep_period) * share_plane + dst] = behz_round(x, b, b.lv[1], mods);
+    }
+  }
   const u64 q1 = mods[1].q, half = q1 >> 1, half0 = reduce64(half, q0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -398,8 +431,11 @@ extern "C" int mmh_add_plain(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, 
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N;
   const int limbs = limbs_of(ctx, lv);
-  if (d_out != d_cts)
-    MMH_HIP(hipMemcpyAsync(d_out, d_cts, n * 2 * limbs * N * 8, hipMemcpyDeviceToDevice, s));
+  (void)limbs;
+  if (d_out != d_cts) {
+    LAUNCH(add_plain_copy_kernel, n * N, s, d_cts, d_pts, d_out, n * N, ctx->logN, sub, ctx->bfv, lv, ctx->d_mods);
+    return MMH_OK;
+  }
   LAUNCH(add_plain_kernel, n * N, s, d_out, d_pts, n * N, ctx->logN, sub, ctx->bfv, lv, ctx->d_mods);
   return MMH_OK;
 }
@@ -632,14 +668,15 @@ extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t
 // addRandomMask + truncate_for_decryption + removeUnusedCoeffs of the shipped USE_APPROX_RESHARE build
 // (hom_conv2d_ss.cc:761-788, :698-703, :800-851; hom_fc_ss.cc:473-561) on n accumulated ciphertexts:
 // d_acc [n][2][2][N] at the first level, in NTT or coefficient form (consumed), d_out [n][2][N] at the last.
-// Six launches: inverse NTT of acc, forward NTT of u straight from the signed samples, pk product,
+// Five launches: inverse NTT of acc, forward NTT of u straight from the signed samples, pk product,
 // inverse NTT, and one pass that mod-switches, adds the encryption of zero and e1, subtracts the mask,
-// truncates and clears the unused coefficients.  Same bits as the step-by-step entry points.
+// truncates, clears the unused coefficients and (d_share_dst [keep_period][N]: target index or -1) scatters
+// the mask's scale-and-round into the share tensor d_share_out [n / keep_period][share_plane].  Same bits as the step-by-step entry points.
 namespace mmh {
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
                         const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
-                        u64 *d_out, hipStream_t s) {
+                        u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out) {
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   const size_t N = ctx->N;
@@ -652,7 +689,7 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   CHECK_RC(ntt_dispatch(ctx, true, zero.as<u64>(), n * 2, 1, 0, s));
   LAUNCH(reshare_finish_kernel, n * N, s, d_acc, zero.as<u64>(), d_e1, d_mask, d_out, n * N, ctx->logN,
          ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep, keep_period ? keep_period : 1,
-         ctx->d_mods);
+         ctx->d_mods, d_share_dst, share_plane, d_share_out, ctx->bfv);
   return MMH_OK;
 }
 }  // namespace mmh

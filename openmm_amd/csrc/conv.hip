@@ -15,7 +15,7 @@ int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n
                       hipStream_t s);
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
-                        u64 *d_out, hipStream_t s);
+                        u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out);
 int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
                         int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
                         hipStream_t s);
@@ -46,6 +46,7 @@ struct mmh_conv_plan {
   uint32_t *d_tgt_dst = nullptr;         // [n_targets] offset inside one out_h x out_w plane
   uint32_t *d_tgt_slice = nullptr;       // [n_targets] spatial window the target belongs to
   uint8_t *d_keep = nullptr;             // [n_spatial][N] coefficients that survive remove_unused_coeffs
+  int *d_share_dst = nullptr;            // [n_spatial][N] offset of a target coefficient in the result plane, else -1
   // 1x1 filters with few channels per polynomial: multiply-accumulate as a mod-q matrix product over
   // channels (pointwise_mac below) instead of transforming M*Cs sparse filter polynomials
   bool pointwise = false;
@@ -59,6 +60,7 @@ struct mmh_conv_filters {
   uint64_t *f_ntt = nullptr;                 // transform route: [M*Cs][2][N] lifted, NTT form
   uint32_t *wp = nullptr, *flag = nullptr;   // 1x1 route: biased weights, "needs the general form" flag
   uint64_t *wl = nullptr;                    //            lifted 64-bit weights
+  int form = -1;                             //            0 fast, 1 general (read back once at prepare), -1 unknown
 };
 
 namespace mmh {
@@ -390,7 +392,7 @@ static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, c
 }
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const u32 *flag,
-                             u64 *acc, hipStream_t s) {
+                             u64 *acc, hipStream_t s, int form = -1) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const PwSizes z = pw_sizes(p);
@@ -401,12 +403,13 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     hipLaunchKernelGGL(kern, dim3((unsigned)(cols / 64), (unsigned)(z.Mpad / tf)), dim3(256), 0, s, image, wp, wl, flag,
                        p->d_keep, p->d_pw_chan, acc, z.M, z.Mpad, z.Cpad, S, ctx->logN, ctx->d_mods);
   };
+  // the device-side flag picks the instantiation that runs; a caller that already knows it skips the other
   if (wide) {
-    launch(pw_gemm_kernel<true, 16>, 64);
-    launch(pw_gemm_kernel<false, 16>, 64);
+    if (form != 1) launch(pw_gemm_kernel<true, 16>, 64);
+    if (form != 0) launch(pw_gemm_kernel<false, 16>, 64);
   } else {
-    launch(pw_gemm_kernel<true, 8>, 32);
-    launch(pw_gemm_kernel<false, 8>, 32);
+    if (form != 1) launch(pw_gemm_kernel<true, 8>, 32);
+    if (form != 0) launch(pw_gemm_kernel<false, 8>, 32);
   }
   MMH_HIP(hipGetLastError());
   return MMH_OK;
@@ -549,6 +552,8 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     hoff += last_h;
   }
   p->n_targets = coef.size();
+  std::vector<int> share_dst(p->n_spatial * (size_t)N, -1);
+  for (size_t g = 0; g < coef.size(); ++g) share_dst[(size_t)slice[g] * N + coef[g]] = (int)dst[g];
   // 1x1 filters, few channels per polynomial: channel-wise matrix product (MMH_CONV_POINTWISE=0 keeps
   // the transform route for A/B measurements)
   const char *pw_env = getenv("MMH_CONV_POINTWISE");
@@ -565,7 +570,7 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
   }
   if ((rc = upload_vec(p, wins, &p->d_windows)) || (rc = upload_vec(p, coef, &p->d_tgt_coef)) ||
       (rc = upload_vec(p, dst, &p->d_tgt_dst)) || (rc = upload_vec(p, slice, &p->d_tgt_slice)) ||
-      (rc = upload_vec(p, keep, &p->d_keep))) {
+      (rc = upload_vec(p, keep, &p->d_keep)) || (rc = upload_vec(p, share_dst, &p->d_share_dst))) {
     mmh_conv_plan_destroy(p);
     return rc;
   }
@@ -675,7 +680,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
   if (!rc && p->pointwise && prepared)
-    rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->flag, (u64 *)acc, s);
+    rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->flag, (u64 *)acc, s,
+                           prepared->form);
   if (!rc && p->pointwise && !prepared)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s);
   if (!rc && !p->pointwise && !prepared && d_filters_raw)
@@ -691,10 +697,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
     rc = reshare_tail_approx(ctx, (u64 *)acc, !p->pointwise, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
-                             d_out_cts, s);
-    if (!rc)
-      rc = launch_share_from_mask(ctx, d_mask, d_out_share, M, p->n_targets, S, (size_t)(p->out_h * p->out_w),
-                                  p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+                             d_out_cts, s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share);
   }
   if (exact) {
     // USE_APPROX_RESHARE=0: uniform noise on c0 first, e0 kept, the mask is a plaintext mod t subtracted
@@ -773,6 +776,13 @@ extern "C" int mmh_conv_filters_prepare(const mmh_conv_plan *p, const uint64_t *
     own((void **)&f->wl, (size_t)z.Cpad * z.Mpad * 16);
     own((void **)&f->flag, 4);
     if (!rc) rc = pointwise_weights(p, d_filters, nullptr, f->wp, f->wl, f->flag, s);
+    if (!rc) {  // model-load time: one synchronous read of which weight form the layer needs
+      u32 general = 0;
+      if (hipMemcpyAsync(&general, f->flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess)
+        rc = MMH_ERR_INTERNAL;
+      f->form = general ? 1 : 0;
+    }
   } else {
     const size_t M = (size_t)p->meta.n_filters, Cs = p->n_cslices;
     own((void **)&f->f_ntt, M * Cs * 2 * ctx->N * 8);
