@@ -1,0 +1,178 @@
+// Layer adapters between the networks' NHWC arrays and CheetahLinear / Truncation
+// (SCI/src/library_fixed_uniform_cheetah.cpp:70-600); see include/mm_gemini/library.h.
+#include "mm_gemini/library.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <stdexcept>
+#include <vector>
+
+namespace mm {
+using gemini::CheetahLinear;
+using gemini::Padding;
+using gemini::Tensor;
+using gemini::TensorShape;
+
+namespace {
+thread_local Library *g_current = nullptr;
+const int kServer = 1;
+}  // namespace
+
+void Library::Bind(Library *lib) { g_current = lib; }
+Library &Library::Current() {
+  if (!g_current) throw std::logic_error("mm::Library: no library bound to this thread");
+  return *g_current;
+}
+
+// :70-135.  One fc call per input row; the weight matrix is transposed into (outputs x inputs).
+void Library::MatMul2D(int32_t d0, int32_t d1, int32_t d2, const intType *mat_A, const intType *mat_B, intType *mat_C,
+                       bool is_A_weight_matrix) const {
+  const int64_t in_rows = is_A_weight_matrix ? d1 : d0, in_cols = is_A_weight_matrix ? d2 : d1;
+  const int64_t w_rows = is_A_weight_matrix ? d0 : d1, w_cols = is_A_weight_matrix ? d1 : d2;
+  CheetahLinear::FCMeta meta;
+  meta.input_shape = TensorShape({in_cols});
+  meta.weight_shape = TensorShape({w_cols, w_rows});  // transposed
+  meta.is_shared_input = kIsSharedInput;
+  const intType *weight_mat = is_A_weight_matrix ? mat_A : mat_B, *input_mat = is_A_weight_matrix ? mat_B : mat_A;
+  Tensor<intType> weight_matrix;
+  if (cheetah_linear->party() == kServer) {
+    weight_matrix.Reshape(meta.weight_shape);
+    for (int64_t r = 0; r < w_rows; ++r)
+      for (int64_t c = 0; c < w_cols; ++c) weight_matrix.data()[c * w_rows + r] = getRingElt(weight_mat[r * w_cols + c]);
+  }
+  for (int64_t r = 0; r < in_rows; ++r) {
+    const intType *input_row = input_mat + r * in_cols;
+    Tensor<intType> input_vector;
+    if (meta.is_shared_input) {
+      input_vector = Tensor<intType>::Wrap(const_cast<intType *>(input_row), meta.input_shape);
+    } else {
+      input_vector.Reshape(meta.input_shape);
+      std::transform(input_row, input_row + in_cols, input_vector.data(), [this](uint64_t v) { return getRingElt(v); });
+    }
+    Tensor<uint64_t> out_vec;
+    cheetah_linear->fc(input_vector, weight_matrix, meta, out_vec);
+    std::copy_n(out_vec.data(), out_vec.NumElements(), mat_C + r * in_cols);  // :126-127, as written
+  }
+  if (cheetah_linear->party() == kServer) cheetah_linear->safe_erase(weight_matrix.data(), weight_matrix.NumElements());
+}
+
+// :216-300
+void Library::Conv2DWrapper(signedIntType N, signedIntType H, signedIntType W, signedIntType CI, signedIntType FH,
+                            signedIntType FW, signedIntType CO, signedIntType zPadHLeft, signedIntType zPadHRight,
+                            signedIntType zPadWLeft, signedIntType zPadWRight, signedIntType strideH,
+                            signedIntType /*strideW*/, intType *inputArr, intType *filterArr, intType *outArr) const {
+  if (zPadWLeft < zPadWRight) std::swap(zPadWLeft, zPadWRight);
+  if (zPadHLeft < zPadHRight) std::swap(zPadHLeft, zPadHRight);
+  const signedIntType newH = (H + zPadHLeft + zPadHRight - FH) / strideH + 1;
+  const signedIntType newW = (W + zPadWLeft + zPadWRight - FW) / strideH + 1;
+  CheetahLinear::ConvMeta meta;
+  meta.ishape = TensorShape({CI, H, W});
+  meta.fshape = TensorShape({CI, FH, FW});
+  meta.n_filters = (size_t)CO;
+  meta.padding = (zPadHLeft + zPadHRight + zPadWLeft + zPadWRight) == 0 ? Padding::VALID : Padding::SAME;
+  meta.stride = (size_t)strideH;
+  meta.is_shared_input = kIsSharedInput;
+  std::vector<Tensor<intType>> filters((size_t)CO, Tensor<intType>(meta.fshape));
+  for (signedIntType i = 0; i < FH; ++i)
+    for (signedIntType j = 0; j < FW; ++j)
+      for (signedIntType k = 0; k < CI; ++k)
+        for (signedIntType p = 0; p < CO; ++p)
+          filters[(size_t)p](k, i, j) = getRingElt(filterArr[((i * FW + j) * CI + k) * CO + p]);
+  for (signedIntType b = 0; b < N; ++b) {
+    Tensor<intType> image(meta.ishape), out_tensor;
+    for (signedIntType j = 0; j < H; ++j)
+      for (signedIntType k = 0; k < W; ++k)
+        for (signedIntType p = 0; p < CI; ++p) image(p, j, k) = getRingElt(inputArr[((b * H + j) * W + k) * CI + p]);
+    cheetah_linear->conv2d(image, filters, meta, out_tensor);
+    for (signedIntType j = 0; j < newH; ++j)
+      for (signedIntType k = 0; k < newW; ++k)
+        for (signedIntType p = 0; p < CO; ++p) outArr[((b * newH + j) * newW + k) * CO + p] = out_tensor(p, j, k);
+  }
+}
+
+// :429-490: channel-wise scaling through bn_direct, then the bias share is added
+void Library::BatchNorm(int32_t B, int32_t H, int32_t W, int32_t C, const intType *inputArr, const intType *scales,
+                        const intType *bias, intType *outArr) const {
+  CheetahLinear::BNMeta meta;
+  meta.target_base_mod = prime_mod;
+  meta.is_shared_input = kIsSharedInput;
+  meta.ishape = TensorShape({C, H, W});
+  Tensor<intType> scale_vec(TensorShape({C}));
+  if (cheetah_linear->party() == kServer)
+    std::transform(scales, scales + C, scale_vec.data(), [this](uint64_t v) { return getRingElt(v); });
+  Tensor<intType> in_tensor(meta.ishape), out_tensor;
+  for (int32_t b = 0; b < B; ++b) {
+    for (int32_t h = 0; h < H; ++h)
+      for (int32_t w = 0; w < W; ++w)
+        for (int32_t c = 0; c < C; ++c) in_tensor(c, h, w) = getRingElt(inputArr[(((int64_t)b * H + h) * W + w) * C + c]);
+    cheetah_linear->bn_direct(in_tensor, scale_vec, meta, out_tensor);
+    for (int32_t h = 0; h < H; ++h)
+      for (int32_t w = 0; w < W; ++w)
+        for (int32_t c = 0; c < C; ++c)
+          outArr[(((int64_t)b * H + h) * W + w) * C + c] = SecretAdd(out_tensor(c, h, w), bias[c]);
+  }
+  if (cheetah_linear->party() == kServer) cheetah_linear->safe_erase(scale_vec.data(), scale_vec.NumElements());
+}
+
+// :492-565.  The reference splits the range over num_threads Truncation objects (each with its own
+// socket); the conversions here are single batched device calls, so one object takes the whole range.
+void Library::Ring2Field(int32_t size, intType *inArr, intType *outputArr) const {
+  truncation->ring_to_field(size, inArr, outputArr, bitlength, field_mod);
+}
+void Library::Field2Ring(int32_t size, intType *inArr, intType *outputArr) const {
+  truncation->field_to_ring(size, inArr, outputArr, field_mod, bitlength);
+}
+void Library::Field2Ring_with_Truncate(int32_t size, intType *inArr, intType *outputArr) const {
+  truncation->field_to_ring_with_truncate(size, inArr, outputArr, field_mod, bitlength, kScale);
+}
+
+// :567-600: ring -> field, SIMD product with the model's scale vector, field -> ring with the free truncation
+void Library::ElemWiseActModelVectorMult(int32_t size, intType *inArr, intType *multArrVec, intType *outputArr) const {
+  CheetahLinear::BNMeta meta;
+  meta.target_base_mod = field_mod;
+  meta.is_shared_input = kIsSharedInput;
+  meta.vec_shape = TensorShape({size});
+  Tensor<intType> field_in(meta.vec_shape), field_scale(meta.vec_shape), field_out;
+  if (meta.is_shared_input) {
+    Ring2Field(size, inArr, field_in.data());
+  } else {
+    std::transform(inArr, inArr + size, field_in.data(), [this](uint64_t v) { return getFieldElt((int64_t)v); });
+  }
+  if (cheetah_linear->party() == kServer)
+    std::transform(multArrVec, multArrVec + size, field_scale.data(),
+                   [this](uint64_t v) { return getFieldElt((int64_t)v); });
+  cheetah_linear->bn(field_in, field_scale, meta, field_out);
+  Field2Ring_with_Truncate(size, field_out.data(), outputArr);
+  if (cheetah_linear->party() == kServer) cheetah_linear->safe_erase(field_scale.data(), field_scale.NumElements());
+}
+
+}  // namespace mm
+
+void MatMul2D(int32_t d0, int32_t d1, int32_t d2, const mm::intType *mat_A, const mm::intType *mat_B,
+              mm::intType *mat_C, bool is_A_weight_matrix) {
+  mm::Library::Current().MatMul2D(d0, d1, d2, mat_A, mat_B, mat_C, is_A_weight_matrix);
+}
+void Conv2DWrapper(mm::signedIntType N, mm::signedIntType H, mm::signedIntType W, mm::signedIntType CI,
+                   mm::signedIntType FH, mm::signedIntType FW, mm::signedIntType CO, mm::signedIntType zPadHLeft,
+                   mm::signedIntType zPadHRight, mm::signedIntType zPadWLeft, mm::signedIntType zPadWRight,
+                   mm::signedIntType strideH, mm::signedIntType strideW, mm::intType *inputArr,
+                   mm::intType *filterArr, mm::intType *outArr) {
+  mm::Library::Current().Conv2DWrapper(N, H, W, CI, FH, FW, CO, zPadHLeft, zPadHRight, zPadWLeft, zPadWRight, strideH,
+                                       strideW, inputArr, filterArr, outArr);
+}
+void BatchNorm(int32_t B, int32_t H, int32_t W, int32_t C, const mm::intType *inputArr, const mm::intType *scales,
+               const mm::intType *bias, mm::intType *outArr) {
+  mm::Library::Current().BatchNorm(B, H, W, C, inputArr, scales, bias, outArr);
+}
+void Ring2Field(int32_t size, mm::intType *inArr, mm::intType *outputArr) {
+  mm::Library::Current().Ring2Field(size, inArr, outputArr);
+}
+void Field2Ring(int32_t size, mm::intType *inArr, mm::intType *outputArr) {
+  mm::Library::Current().Field2Ring(size, inArr, outputArr);
+}
+void Field2Ring_with_Truncate(int32_t size, mm::intType *inArr, mm::intType *outputArr) {
+  mm::Library::Current().Field2Ring_with_Truncate(size, inArr, outputArr);
+}
+void ElemWiseActModelVectorMult(int32_t size, mm::intType *inArr, mm::intType *multArrVec, mm::intType *outputArr) {
+  mm::Library::Current().ElemWiseActModelVectorMult(size, inArr, multArrVec, outputArr);
+}

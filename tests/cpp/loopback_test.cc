@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "mm_gemini/cheetah_linear.h"
+#include "mm_gemini/library.h"
 #include "mm_gemini/truncation.h"
 
 using gemini::CheetahLinear;
@@ -270,6 +271,111 @@ int main(int argc, char **argv) {
       A2.linear->conv2d(bad, filters, meta, out[0]);
     } catch (const std::invalid_argument &) { threw = true; }
     EXPECT(threw, "conv2d shape mismatch throws std::invalid_argument");
+  }
+
+  // ---- layer adapters with the reference's signatures (library_fixed_uniform_cheetah.cpp:70-600):
+  // NHWC / [FH][FW][CI][CO] arrays in, shares out, both parties through the free functions ----------
+  {
+    const int l = 37, ks = 12;
+    const u64 m37 = (1ULL << l) - 1;
+    Party A3{1}, B3{2};
+    auto io3 = mm::LoopbackIO::MakePair();
+    A3.io = std::move(io3.first);
+    B3.io = std::move(io3.second);
+    auto box3 = std::make_shared<mm::IdealCOT::Mailbox>();
+    A3.cot.reset(new mm::IdealCOT(box3, 3));
+    B3.cot.reset(new mm::IdealCOT(box3, 4));
+    mm::Library lib[2];
+    both(A3, B3, [&](Party &p) {
+      p.linear.reset(new CheetahLinear(p.id, p.io.get(), 1ULL << l));
+      p.trunc.reset(new mm::Truncation(p.id, p.cot.get()));
+      mm::Library &L = lib[p.id - 1];
+      L.party = p.id, L.bitlength = l, L.kScale = ks, L.prime_mod = 1ULL << l, L.field_mod = p.linear->field_mod();
+      L.cheetah_linear = p.linear.get(), L.truncation = p.trunc.get();
+    });
+    auto with_lib = [&](const std::function<void(int)> &fn) {
+      both(A3, B3, [&](Party &p) {
+        mm::Library::Bind(&lib[p.id - 1]);
+        fn(p.id - 1);
+      });
+    };
+    // Conv2DWrapper: 1 x 10 x 10 x 5 image (NHWC), 3x3 filters [FH][FW][CI][CO], pads (1,1,1,1), stride 1
+    const int H = 10, CI = 5, CO = 4, FH = 3;
+    std::vector<int64_t> x(H * H * CI), w(FH * FH * CI * CO);
+    std::vector<u64> xs[2] = {std::vector<u64>(x.size()), std::vector<u64>(x.size())}, wa(w.size());
+    for (size_t i = 0; i < x.size(); ++i) {
+      x[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      xs[0][i] = rng() & m37, xs[1][i] = ((u64)x[i] - xs[0][i]) & m37;
+    }
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12), wa[i] = (u64)w[i];
+    std::vector<u64> co[2] = {std::vector<u64>(H * H * CO), std::vector<u64>(H * H * CO)};
+    with_lib([&](int s) { Conv2DWrapper(1, H, H, CI, FH, FH, CO, 1, 1, 1, 1, 1, 1, xs[s].data(), wa.data(), co[s].data()); });
+    bool ok = true;
+    for (int oh = 0; oh < H; ++oh)
+      for (int ow = 0; ow < H; ++ow)
+        for (int m_ = 0; m_ < CO; ++m_) {
+          int64_t acc = 0;
+          for (int r = 0; r < FH; ++r)
+            for (int q = 0; q < FH; ++q)
+              for (int c = 0; c < CI; ++c) {
+                const int ih = oh + r - 1, iw = ow + q - 1;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= H) continue;
+                acc += w[((r * FH + q) * CI + c) * CO + m_] * x[(ih * H + iw) * CI + c];
+              }
+          const size_t o = (size_t)(oh * H + ow) * CO + m_;
+          ok &= std::llabs(to_signed(co[0][o] + co[1][o], l) - acc) <= 1;
+        }
+    EXPECT(ok, "Conv2DWrapper (NHWC arrays, free function): |err| <= 1");
+    // MatMul2D: 1 x 40 input row times a 40 x 7 weight matrix (B is the weight matrix)
+    const int d1 = 40, d2 = 7;
+    std::vector<int64_t> a(d1), bmat(d1 * d2);
+    std::vector<u64> as[2] = {std::vector<u64>(d1), std::vector<u64>(d1)}, bw_(d1 * d2);
+    for (int i = 0; i < d1; ++i) {
+      a[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      as[0][i] = rng() & m37, as[1][i] = ((u64)a[i] - as[0][i]) & m37;
+    }
+    for (int i = 0; i < d1 * d2; ++i) bmat[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12), bw_[i] = (u64)bmat[i];
+    std::vector<u64> mo[2] = {std::vector<u64>(d1, 0), std::vector<u64>(d1, 0)};  // row stride = input cols (:126)
+    with_lib([&](int s) { MatMul2D(1, d1, d2, as[s].data(), bw_.data(), mo[s].data(), false); });
+    ok = true;
+    for (int j = 0; j < d2; ++j) {
+      int64_t acc = 0;
+      for (int i = 0; i < d1; ++i) acc += a[i] * bmat[i * d2 + j];
+      ok &= std::llabs(to_signed(mo[0][j] + mo[1][j], l) - acc) <= 1;
+    }
+    EXPECT(ok, "MatMul2D (row vector x weight matrix): |err| <= 1");
+    // ElemWiseActModelVectorMult: ring -> field, SIMD product with the model vector, field -> ring >> kScale
+    const int nv = 5000;
+    std::vector<int64_t> v(nv), sc(nv);
+    std::vector<u64> vs[2] = {std::vector<u64>(nv), std::vector<u64>(nv)}, scu(nv), eo[2] = {std::vector<u64>(nv), std::vector<u64>(nv)};
+    for (int i = 0; i < nv; ++i) {
+      v[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12), sc[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      vs[0][i] = rng() & m37, vs[1][i] = ((u64)v[i] - vs[0][i]) & m37, scu[i] = (u64)sc[i];
+    }
+    with_lib([&](int s) { ElemWiseActModelVectorMult(nv, vs[s].data(), scu.data(), eo[s].data()); });
+    ok = true;
+    for (int i = 0; i < nv; ++i) {
+      const int64_t want = (v[i] * sc[i]) >> ks;  // arithmetic shift = floor
+      ok &= std::llabs(to_signed(eo[0][i] + eo[1][i], l) - want) <= 1;
+    }
+    EXPECT(ok, "ElemWiseActModelVectorMult: (x * scale) >> kScale within 1");
+    // BatchNorm (bn_direct + bias share): 1 x 6 x 6 x 3, exact
+    const int bh = 6, bc = 3;
+    std::vector<int64_t> bx(bh * bh * bc), bs(bc), bb(bc);
+    std::vector<u64> bxs[2] = {std::vector<u64>(bx.size()), std::vector<u64>(bx.size())}, bsu(bc), bbs[2] = {std::vector<u64>(bc), std::vector<u64>(bc)};
+    std::vector<u64> bo[2] = {std::vector<u64>(bx.size()), std::vector<u64>(bx.size())};
+    for (size_t i = 0; i < bx.size(); ++i) {
+      bx[i] = (int64_t)(rng() % (1 << 13)) - (1 << 12);
+      bxs[0][i] = rng() & m37, bxs[1][i] = ((u64)bx[i] - bxs[0][i]) & m37;
+    }
+    for (int c = 0; c < bc; ++c) {
+      bs[c] = (int64_t)(rng() % (1 << 13)) - (1 << 12), bb[c] = (int64_t)(rng() % (1 << 20));
+      bsu[c] = (u64)bs[c], bbs[0][c] = rng() & m37, bbs[1][c] = ((u64)bb[c] - bbs[0][c]) & m37;
+    }
+    with_lib([&](int s) { BatchNorm(1, bh, bh, bc, bxs[s].data(), bsu.data(), bbs[s].data(), bo[s].data()); });
+    ok = true;
+    for (size_t i = 0; i < bx.size(); ++i) ok &= to_signed(bo[0][i] + bo[1][i], l) == bx[i] * bs[i % bc] + bb[i % bc];
+    EXPECT(ok, "BatchNorm (NHWC, bn_direct + bias): exact");
   }
   std::printf("%s (%d failures)\n", g_fail ? "FAILED" : "ALL PASSED", g_fail);
   return g_fail ? 1 : 0;
