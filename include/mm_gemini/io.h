@@ -9,6 +9,7 @@
 #pragma once
 #include <condition_variable>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -27,26 +28,40 @@ class IOChannel {
   uint64_t counter = 0;  // bytes sent, as sci::IOChannel::counter (io_channel.h:41-45)
 };
 
-// One direction of an in-process byte pipe.
+// One direction of an in-process byte pipe: a queue of message chunks copied at memcpy speed.
 class BytePipe {
  public:
   void push(const void *p, size_t n) {
-    std::lock_guard<std::mutex> g(m_);
+    if (n == 0) return;
     const uint8_t *b = static_cast<const uint8_t *>(p);
-    q_.insert(q_.end(), b, b + n);
+    std::vector<uint8_t> chunk(b, b + n);
+    std::lock_guard<std::mutex> g(m_);
+    bytes_ += n;
+    q_.push_back(std::move(chunk));
     cv_.notify_all();
   }
   void pop(void *p, size_t n) {
+    uint8_t *dst = static_cast<uint8_t *>(p);
     std::unique_lock<std::mutex> g(m_);
-    cv_.wait(g, [&] { return q_.size() >= n; });
-    std::copy(q_.begin(), q_.begin() + n, static_cast<uint8_t *>(p));
-    q_.erase(q_.begin(), q_.begin() + n);
+    cv_.wait(g, [&] { return bytes_ >= n; });
+    bytes_ -= n;
+    while (n > 0) {
+      std::vector<uint8_t> &front = q_.front();
+      const size_t take = std::min(n, front.size() - head_);
+      std::memcpy(dst, front.data() + head_, take);
+      dst += take, n -= take, head_ += take;
+      if (head_ == front.size()) {
+        q_.pop_front();
+        head_ = 0;
+      }
+    }
   }
 
  private:
   std::mutex m_;
   std::condition_variable cv_;
-  std::deque<uint8_t> q_;
+  std::deque<std::vector<uint8_t>> q_;
+  size_t head_ = 0, bytes_ = 0;  // read offset inside the front chunk, bytes queued
 };
 
 class LoopbackIO : public IOChannel {

@@ -198,22 +198,31 @@ struct CheetahLinear::Impl {
   }
 
   // ---- ciphertext transport: u32 count, then the raw coefficient words (cheetah-api.cpp:11-29) ----
+  // host staging for ciphertext batches (up to 128 MiB per layer): one grow-only buffer per object, so the
+  // pages are touched once and not on every call
+  mutable std::vector<uint64_t> staging;
+  uint64_t *stage(size_t words) const {
+    if (staging.size() < words) staging.resize(words);
+    return staging.data();
+  }
   void send_cts(const Dev &d, size_t n_cts, size_t words_per_ct) const {
-    std::vector<uint64_t> host(n_cts * words_per_ct);
-    d.download(host.data(), host.size());
+    const size_t words = n_cts * words_per_ct;
+    uint64_t *host = stage(words);
+    d.download(host, words);
     uint32_t n = (uint32_t)n_cts;
     io->send_data(&n, sizeof(n));
-    io->send_data(host.data(), host.size() * 8);
+    io->send_data(host, words * 8);
     io->flush();
   }
   Dev recv_cts(size_t expect, size_t words_per_ct) const {
     uint32_t n = 0;
     io->recv_data(&n, sizeof(n));
     if (n != expect) throw std::runtime_error("CheetahLinear: ciphertext count mismatch");
-    std::vector<uint64_t> host((size_t)n * words_per_ct);
-    io->recv_data(host.data(), host.size() * 8);
-    Dev d(host.size());
-    d.upload(host.data(), host.size());
+    const size_t words = (size_t)n * words_per_ct;
+    uint64_t *host = stage(words);
+    io->recv_data(host, words * 8);
+    Dev d(words);
+    d.upload(host, words);
     return d;
   }
 };

@@ -1,0 +1,125 @@
+// Linear layers of a whole network through the layer adapters, both parties in one process
+// (BASELINE.json configs[3-4] in loop-back: the HE-linear part only; the OT-based non-linear layers
+// between them are outside this build).  For every convolution of the network, in the order and with
+// the shapes of networks/main_{sqnet,resnet50}.cpp, both parties call Conv2DWrapper on fresh additive
+// shares (NHWC) with synthetic weights; a sample of outputs is reconstructed and compared with the
+// cleartext convolution (|err| <= 1, library_fixed_uniform_cheetah.cpp:199).  Prints per-network totals.
+//   usage: network_linear [sqnet|resnet50] [samples per layer = 512]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "mm_gemini/library.h"
+
+using u64 = uint64_t;
+struct Shape { int C, H, W, fh, fw, M, pad, stride, count; };  // pad: zPad on each side (0 = VALID)
+
+static const Shape kSqnet[] = {
+    {3, 227, 227, 3, 3, 64, 0, 2, 1}, {64, 56, 56, 1, 1, 16, 0, 1, 1}, {16, 56, 56, 1, 1, 64, 0, 1, 2},
+    {16, 56, 56, 3, 3, 64, 1, 1, 2}, {128, 56, 56, 1, 1, 16, 0, 1, 1}, {128, 27, 27, 1, 1, 32, 0, 1, 1},
+    {32, 27, 27, 1, 1, 128, 0, 1, 2}, {32, 27, 27, 3, 3, 128, 1, 1, 2}, {256, 27, 27, 1, 1, 32, 0, 1, 1},
+    {256, 13, 13, 1, 1, 48, 0, 1, 1}, {48, 13, 13, 1, 1, 192, 0, 1, 2}, {48, 13, 13, 3, 3, 192, 1, 1, 2},
+    {384, 13, 13, 1, 1, 48, 0, 1, 1}, {384, 13, 13, 1, 1, 64, 0, 1, 1}, {64, 13, 13, 1, 1, 256, 0, 1, 2},
+    {64, 13, 13, 3, 3, 256, 1, 1, 2}, {512, 13, 13, 1, 1, 64, 0, 1, 1}, {512, 13, 13, 1, 1, 1000, 0, 1, 1}};
+static const Shape kResnet50[] = {
+    {3, 230, 230, 7, 7, 64, 0, 2, 1}, {64, 56, 56, 1, 1, 256, 0, 1, 4}, {64, 56, 56, 1, 1, 64, 0, 1, 1},
+    {64, 56, 56, 3, 3, 64, 1, 1, 3}, {256, 56, 56, 1, 1, 64, 0, 1, 2}, {256, 56, 56, 1, 1, 512, 0, 2, 1},
+    {256, 56, 56, 1, 1, 128, 0, 1, 1}, {128, 58, 58, 3, 3, 128, 0, 2, 1}, {128, 28, 28, 1, 1, 512, 0, 1, 4},
+    {512, 28, 28, 1, 1, 128, 0, 1, 3}, {128, 28, 28, 3, 3, 128, 1, 1, 3}, {512, 28, 28, 1, 1, 1024, 0, 2, 1},
+    {512, 28, 28, 1, 1, 256, 0, 1, 1}, {256, 30, 30, 3, 3, 256, 0, 2, 1}, {256, 14, 14, 1, 1, 1024, 0, 1, 6},
+    {1024, 14, 14, 1, 1, 256, 0, 1, 5}, {256, 14, 14, 3, 3, 256, 1, 1, 5}, {1024, 14, 14, 1, 1, 2048, 0, 2, 1},
+    {1024, 14, 14, 1, 1, 512, 0, 1, 1}, {512, 16, 16, 3, 3, 512, 0, 2, 1}, {512, 7, 7, 1, 1, 2048, 0, 1, 3},
+    {2048, 7, 7, 1, 1, 512, 0, 1, 2}, {512, 7, 7, 3, 3, 512, 1, 1, 2}};
+
+static int64_t to_signed(u64 v, int bw) {
+  v &= (1ULL << bw) - 1;
+  return (v >> (bw - 1)) ? (int64_t)v - (int64_t)(1ULL << bw) : (int64_t)v;
+}
+
+int main(int argc, char **argv) {
+  const bool resnet = argc > 1 && !std::strcmp(argv[1], "resnet50");
+  const int samples = argc > 2 ? std::atoi(argv[2]) : 512;
+  const Shape *net = resnet ? kResnet50 : kSqnet;
+  const size_t n_shapes = resnet ? sizeof(kResnet50) / sizeof(Shape) : sizeof(kSqnet) / sizeof(Shape);
+  const int l = 37;
+  const u64 mask = (1ULL << l) - 1;
+  std::mt19937_64 rng(0x4D264D);
+
+  auto ios = mm::LoopbackIO::MakePair();
+  std::unique_ptr<mm::LoopbackIO> io[2] = {std::move(ios.first), std::move(ios.second)};
+  std::unique_ptr<gemini::CheetahLinear> linear[2];
+  mm::Library lib[2];
+  auto both = [&](const std::function<void(int)> &fn) {
+    std::exception_ptr e[2];
+    std::thread t0([&] { try { mm::Library::Bind(&lib[0]); fn(0); } catch (...) { e[0] = std::current_exception(); } });
+    std::thread t1([&] { try { mm::Library::Bind(&lib[1]); fn(1); } catch (...) { e[1] = std::current_exception(); } });
+    t0.join();
+    t1.join();
+    for (auto &x : e)
+      if (x) std::rethrow_exception(x);
+  };
+  both([&](int s) {
+    linear[s].reset(new gemini::CheetahLinear(s + 1, io[s].get(), 1ULL << l));
+    lib[s].party = s + 1, lib[s].bitlength = l, lib[s].kScale = 12, lib[s].prime_mod = 1ULL << l;
+    lib[s].field_mod = linear[s]->field_mod(), lib[s].cheetah_linear = linear[s].get();
+  });
+
+  int layers = 0, failures = 0;
+  double total_ms = 0;
+  for (size_t k = 0; k < n_shapes; ++k) {
+    const Shape &sh = net[k];
+    const int oh = (sh.H + 2 * sh.pad - sh.fh) / sh.stride + 1, ow = (sh.W + 2 * sh.pad - sh.fw) / sh.stride + 1;
+    const size_t n_in = (size_t)sh.H * sh.W * sh.C, n_w = (size_t)sh.fh * sh.fw * sh.C * sh.M, n_out = (size_t)oh * ow * sh.M;
+    std::vector<int64_t> x(n_in), w(n_w);
+    std::vector<u64> xs[2] = {std::vector<u64>(n_in), std::vector<u64>(n_in)}, wu(n_w);
+    std::vector<u64> out[2] = {std::vector<u64>(n_out), std::vector<u64>(n_out)};
+    for (size_t i = 0; i < n_in; ++i) {
+      x[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11);
+      xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
+    }
+    for (size_t i = 0; i < n_w; ++i) w[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11) + (i % 7 == 0), wu[i] = (u64)w[i];
+    const bool first = k == 0;  // the networks run their first layer on the client's plain input
+    if (first) {
+      for (size_t i = 0; i < n_in; ++i) xs[1][i] = (u64)x[i] & mask, xs[0][i] = 0;
+    }
+    lib[0].kIsSharedInput = lib[1].kIsSharedInput = !first;
+    double ms = 0;
+    for (int rep = 0; rep < sh.count; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      both([&](int s) {
+        Conv2DWrapper(1, sh.H, sh.W, sh.C, sh.fh, sh.fw, sh.M, sh.pad, sh.pad, sh.pad, sh.pad, sh.stride, sh.stride,
+                      xs[s].data(), wu.data(), out[s].data());
+      });
+      ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      ++layers;
+    }
+    bool ok = true;
+    for (int t = 0; t < samples && ok; ++t) {
+      const int y = (int)(rng() % oh), xx = (int)(rng() % ow), m = (int)(rng() % sh.M);
+      int64_t acc = 0;
+      for (int r = 0; r < sh.fh; ++r)
+        for (int q = 0; q < sh.fw; ++q) {
+          const int ih = y * sh.stride + r - sh.pad, iw = xx * sh.stride + q - sh.pad;
+          if (ih < 0 || ih >= sh.H || iw < 0 || iw >= sh.W) continue;
+          for (int c = 0; c < sh.C; ++c)
+            acc += w[(((size_t)r * sh.fw + q) * sh.C + c) * sh.M + m] * x[((size_t)ih * sh.W + iw) * sh.C + c];
+        }
+      const size_t o = ((size_t)y * ow + xx) * sh.M + m;
+      ok = std::llabs(to_signed(out[0][o] + out[1][o], l) - acc) <= 1;
+    }
+    if (!ok) ++failures;
+    std::printf("%s conv %4dx%3dx%3d %dx%d -> %4d s%d x%d: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", sh.C, sh.H,
+                sh.W, sh.fh, sh.fw, sh.M, sh.stride, sh.count, ms);
+    total_ms += ms;
+  }
+  std::printf("%s: %d convolutions through Conv2DWrapper, both parties in-process, %.1f ms in total (host tensors in,\n"
+              "host tensors out, encryption, transport through a byte pipe and decryption included)\n",
+              resnet ? "ResNet50" : "SqueezeNet", layers, total_ms);
+  std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL PASSED", failures);
+  return failures ? 1 : 0;
+}

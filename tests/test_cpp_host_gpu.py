@@ -18,6 +18,17 @@ def test_cpp_loopback_acceptance(args):
     assert "FAIL" not in r.stdout.replace("FAILED", "")
 
 
+@pytest.mark.gpu
+def test_squeezenet_linear_layers_through_the_layer_adapters():
+    """all 26 SqueezeNet convolutions through Conv2DWrapper (NHWC arrays, both parties in-process),
+    sampled outputs within 1 of the cleartext convolution"""
+    exe = os.path.join(ROOT, "tests", "cpp", "network_linear")
+    assert os.path.exists(exe), "build it with __graft_entry__.build() (make -C tests/cpp)"
+    r = subprocess.run([exe, "sqnet", "128"], capture_output=True, text=True, timeout=280)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout and "26 convolutions" in r.stdout
+
+
 def test_host_library_links_without_gpu():
     """CPU: libmm_gemini.so loads and resolves against libmm_hip.so"""
     import ctypes
