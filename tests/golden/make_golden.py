@@ -66,6 +66,17 @@ def build():
                        rns_uniform(c, SEED + 50, cv.n_out, 1)[:, 0])
     out["conv_5x12x12_3x3_same"] = {"filters": digest(cv.encode_filters(f)), "out_cts": digest(oc), "share": digest(sh),
                                     "decrypted": digest(cv.decrypt(np.ascontiguousarray(sk[:1]), oc))}
+    # a 1x1 layer: the HIP side serves it through its coefficient-form product route
+    pv = ConvOracle(c, (6, 14, 14), (6, 1, 1), 4, 0, 1, True)
+    img, s0 = uniform_mod(SEED + 70, (6, 14, 14), c.t), uniform_mod(SEED + 71, (6, 14, 14), c.t)
+    s1 = (img - s0) & np.uint64(c.t - 1)
+    f = signed_weights(SEED + 72, (4, 6, 1, 1), 1 << 12, c.t)
+    cts = pv.encrypt_image(sk, s0, rns_uniform(c, SEED + 73, pv.n_in, 2), noise(SEED + 74, (pv.n_in, 4096)))
+    oc, sh = pv.server(cts, pv.encode_image(s1), pv.encode_filters(f), np.ascontiguousarray(pk[:, :1]),
+                       ternary(SEED + 75, (pv.n_out, 4096)), noise(SEED + 76, (pv.n_out, 4096)),
+                       rns_uniform(c, SEED + 77, pv.n_out, 1)[:, 0])
+    out["conv_6x14x14_1x1"] = {"out_cts": digest(oc), "share": digest(sh),
+                               "decrypted": digest(pv.decrypt(np.ascontiguousarray(sk[:1]), oc))}
     big = ConvOracle(c, (64, 56, 56), (64, 3, 3), 64, 1, 1, True)
     (th, tw), tg = big.targets(big.mask_ix, 0, 0)
     out["conv_resnet_geometry"] = {"slice_strides": list(big.slice_strides), "pads": list(big.pads), "n_in": big.n_in,

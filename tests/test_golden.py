@@ -73,3 +73,18 @@ def test_gpu_reproduces_golden_vectors():
     assert _sha(to_host(oc)) == want["conv_5x12x12_3x3_same"]["out_cts"]["sha256"]
     assert _sha(to_host(sh)) == want["conv_5x12x12_3x3_same"]["share"]["sha256"]
     assert _sha(to_host(client.decryptToTensor(oc, meta))) == want["conv_5x12x12_3x3_same"]["decrypted"]["sha256"]
+    # the 1x1 layer from raw weights (served by the coefficient-form product route on the device)
+    meta = Meta((6, 14, 14), (6, 1, 1), 4, 0, 1, True)
+    plan = server.plan(meta)
+    img, s0 = uniform_mod(SEED + 70, (6, 14, 14), t), uniform_mod(SEED + 71, (6, 14, 14), t)
+    s1 = (img - s0) & np.uint64(t - 1)
+    f = signed_weights(SEED + 72, (4, 6, 1, 1), 1 << 12, t)
+    cts = client.encryptImage(to_device(s0), meta, (to_device(rns_uniform(Q, SEED + 73, plan.n_in, 2)),
+                                                    dev_i(noise(SEED + 74, (plan.n_in, N)))))
+    oc, sh = server.conv2DSSFromWeights(cts, server.encodeImage(to_device(s1), meta), to_device(f), meta,
+                                        (dev_i(ternary(SEED + 75, (plan.n_out, N))),
+                                         dev_i(noise(SEED + 76, (plan.n_out, N))),
+                                         to_device(rns_uniform(Q, SEED + 77, plan.n_out, 1)[:, 0])))
+    assert _sha(to_host(oc)) == want["conv_6x14x14_1x1"]["out_cts"]["sha256"]
+    assert _sha(to_host(sh)) == want["conv_6x14x14_1x1"]["share"]["sha256"]
+    assert _sha(to_host(client.decryptToTensor(oc, meta))) == want["conv_6x14x14_1x1"]["decrypted"]["sha256"]
