@@ -366,6 +366,10 @@ __global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restri
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const size_t p = k * 2 + j;
+    if (j == 0 && keep && !keep[((k % keep_period) << logN) + i]) {  // removed coefficient: nothing of it is read
+      out[(p << logN) + i] = 0;
+      continue;
+    }
     u64 last = csub(acc[((p * 2 + 1) << logN) + i] + half, q1);          // divide_and_round_q_last
     const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
     u64 v = mul_mod(sub_mod(acc[((p * 2) << logN) + i], tmp, q0.q), inv_qlast, q0);
@@ -374,9 +378,7 @@ __global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restri
       if (e1) v = add_mod(v, signed_to_mod(e1[idx], q0.q), q0.q);
       v &= mask1;
     } else {
-      v = sub_mod(v, mask[idx], q0.q);
-      const bool kept = !keep || keep[((k % keep_period) << logN) + i];
-      v = kept ? (v & mask0) : 0;
+      v = sub_mod(v, mask[idx], q0.q) & mask0;
     }
     out[(p << logN) + i] = v;
   }

@@ -50,7 +50,9 @@ struct mmh_conv_plan {
   // 1x1 filters with few channels per polynomial: multiply-accumulate as a mod-q matrix product over
   // channels (pointwise_mac below) instead of transforming M*Cs sparse filter polynomials
   bool pointwise = false;
-  mmh::PwChannel *d_pw_chan = nullptr;   // [C rounded up to 32]: input row (channel slice) and rotation of a channel
+  mmh::PwChannel *d_pw_chan = nullptr;   // [C rounded up to 64]: input row (channel slice) and rotation of a channel
+  int *d_pw_live = nullptr;              // [pw_live_tiles] the 64-column tiles the product computes (index = column / 64)
+  size_t pw_live_tiles = 0;
   std::vector<void *> allocs;
 };
 
@@ -60,6 +62,7 @@ struct mmh_conv_filters {
   uint64_t *f_ntt = nullptr;                 // transform route: [M*Cs][2][N] lifted, NTT form
   uint32_t *wp = nullptr, *flag = nullptr;   // 1x1 route: biased weights, "needs the general form" flag
   uint64_t *wl = nullptr;                    //            lifted 64-bit weights
+  uint8_t *w8 = nullptr;                     //            signed byte digits in matrix-core fragment order
   int form = -1;                             //            0 fast, 1 general (read back once at prepare), -1 unknown
 };
 
@@ -170,20 +173,23 @@ int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t g
 // Everything is exact mod q_l, so the kept coefficients equal the per-term multiply_plain schedule bit
 // for bit.  Cheaper than the transform route while wc is small (per output column C scalar MACs against
 // Cs * (2 NTTs + 4 dyadic MACs)); measured break-even near 28 channels per polynomial.
-constexpr int kPwMaxWc = 24;  // measured break-even near 28 channels per polynomial
+constexpr int kPwMaxWc = 160;  // break-even against the transform route
 constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as w + 2^20
 
-// weights [M][C] (mod t) -> biased 32-bit form wp[Cpad][Mpad], lifted 64-bit form wl[2][Cpad][Mpad], and a flag
-// that is raised when some weight does not fit the fast form.  STRIDED: read them back from encoded
-// filter plaintexts instead of the raw tensor.
+// weights [M][C] (mod t) -> biased 32-bit form wp[Cpad][Mpad], lifted 64-bit form wl[2][Cpad][Mpad], signed byte
+// digits w8 in matrix-core fragment order (pw_mfma_kernel), and a flag word: bit 0 when some weight does not
+// fit the fast forms (|w| >= 2^20), bit 1 when some weight needs a third byte digit.  FROM_PTS: read them
+// back from encoded filter plaintexts instead of the raw tensor.
+// w8 layout: [m / 128][k / 64][digit 3][(m % 128) / 16][lane = ((k % 64) / 16) << 4 | m % 16][k % 16].
 template <bool FROM_PTS>
 __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__ src, u32 *__restrict__ wp,
-                                                         u64 *__restrict__ wl, u32 *__restrict__ flag, int M,
-                                                         int Mpad, int C, int Cpad, int wc, int n_cslices, int logN,
+                                                         u64 *__restrict__ wl, uint8_t *__restrict__ w8,
+                                                         u32 *__restrict__ flag, int M, int Mpad, int Mpad128, int C,
+                                                         int Cpad, int Cpad64, int wc, int n_cslices, int logN,
                                                          long origin, long plane, ModC t, u64 thr, u64 q0, u64 q1) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)Cpad * Mpad) return;
-  const int m = (int)(idx % Mpad), ch = (int)(idx / Mpad);
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)Cpad64 * Mpad128) return;
+  const int m = (int)(gid % Mpad128), ch = (int)(gid / Mpad128);
   u64 v = 0;  // filters and channels beyond the real ones weigh nothing
   if (m < M && ch < C) {
     if (FROM_PTS) {
@@ -195,10 +201,28 @@ __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__
   }
   const bool neg = v >= thr;
   const u64 mag = neg ? t.q - v : v;
-  if (mag >= (u64(1) << kPwBiasLog)) atomicOr(flag, 1u);
-  wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
-  wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
-  wl[(size_t)Cpad * Mpad + idx] = neg ? v + (q1 - t.q) : v;      // limb 1
+  const bool fits = mag < (u64(1) << kPwBiasLog);
+  // balanced byte digits of the signed weight: w = d0 + 256 d1 + 65536 d2, d0 and d1 in [-128, 127]
+  const int w = fits ? (neg ? -(int)mag : (int)mag) : 0;
+  const int wb = w + 0x8080;
+  const int d2 = wb >> 16;
+  u32 bits = fits ? 0u : 1u;
+  if (d2 != 0) bits |= 2u;
+  if (bits) atomicOr(flag, bits);
+  {
+    const int kc = ch >> 6, k = ch & 63;
+    const size_t unit = ((((size_t)(m >> 7) * (Cpad64 >> 6) + kc) * 3) * 8 + ((m & 127) >> 4)) * 64 + (((k >> 4) << 4) | (m & 15));
+    uint8_t *dst = w8 + unit * 16 + (k & 15);
+    dst[0] = (uint8_t)((wb & 0xff) ^ 0x80);
+    dst[8 * 64 * 16] = (uint8_t)(((wb >> 8) & 0xff) ^ 0x80);
+    dst[2 * 8 * 64 * 16] = (uint8_t)d2;
+  }
+  if (m < Mpad && ch < Cpad) {
+    const size_t idx = (size_t)ch * Mpad + m;
+    wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
+    wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
+    wl[(size_t)Cpad * Mpad + idx] = neg ? v + (q1 - t.q) : v;      // limb 1
+  }
 }
 
 // Two filters against both halves of one column value: four independent v_mad_u64_u32 in one asm
@@ -251,7 +275,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
                                                       int Mpad, int Cpad, size_t S, int logN,
                                                       const DevMod *__restrict__ mods) {
   constexpr int PER = kPwChunk / 4, TF = 4 * TM;  // channels per wave per staging step, filters per workgroup
-  if ((*flag == 0) != FAST) return;
+  if (((*flag & 1u) == 0) != FAST) return;
   constexpr bool fast = FAST;
   __shared__ u64 tile[2][kPwChunk][64];
   const int lane = threadIdx.x & 63;
@@ -361,38 +385,253 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
     if (mbase + j < M) acc[(size_t)(mbase + j) * cols + col] = res[j];
 }
 
+// ------------------------------------------------------------------ the fast form on the matrix cores
+// With |w| < 2^20 the product W * U mod q is an exact integer matrix product of small digits:
+//   w = sum_a wd_a 256^a (2 or 3 balanced byte digits),  u = sum_j ud_j 256^j (8 balanced byte digits of the
+//   column value, or of its negation for a wrapped coefficient: no mod-q negation is needed),
+//   sum_ch w u = sum_d 256^d * sum_{a+j=d} (sum_ch wd_a ud_j),
+// every inner sum an i8 x i8 -> i32 matrix product (v_mfma_i32_16x16x64_i8; |sum| < 3 * 4096 * 2^14 < 2^28).
+// pw_expand_kernel writes the digits of U once per layer in fragment order, pw_mfma_kernel multiplies.
+// Digit image of a live 64-column tile: [slot][k / 64][digit 8][column / 16][lane = ((k % 64) / 16) << 4 |
+// column % 16][k % 16]: the 16 bytes of a lane are the B operand of one instruction, a 64-channel step of one
+// tile is 32 KiB contiguous.  The byte order inside a lane only has to agree between the two operands.
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr u64 kDigitBias = 0x0080808080808080ull;
+
+__global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ image,
+                                                        const int *__restrict__ live, uint4 *__restrict__ u8,
+                                                        const u32 *__restrict__ flag, int C, int KC, int wc,
+                                                        int origin, int plane, size_t S, int logN) {
+  if (*flag & 1u) return;
+  const size_t c0 = (size_t)live[blockIdx.x] * 64;   // first column of the tile: (sp, c0/c1, limb, i)
+  const int kc = blockIdx.y, N = 1 << logN;
+  const int col = threadIdx.x >> 2, kg = threadIdx.x & 3;
+  const int i = (int)(c0 & (N - 1)) + col;
+  const int pl = (int)((c0 >> logN) & 3);
+  const size_t sp = c0 >> (logN + 2);
+  const u64 *__restrict__ base = image + ((sp * 4 + pl) << logN);
+  const size_t row_step = S * 4 * N;
+  u32 lo[16], hi[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int ch = kc * 64 + kg * 16 + k;
+    u64 v = 0;
+    if (ch < C) {
+      const int row = ch / wc, e = origin - (ch - row * wc) * plane;
+      v = base[(size_t)row * row_step + ((i - e) & (N - 1))];
+      if (i < e) v = 0 - v;  // X^N = -1: wrapped coefficients enter negated, as plain negative integers
+    }
+    const u64 d = (v + kDigitBias) ^ kDigitBias;
+    lo[k] = (u32)d, hi[k] = (u32)(d >> 32);
+  }
+  // byte j of the 16 values -> 16 bytes: 4x4 byte transposes
+  uint4 *__restrict__ out = u8 + (((size_t)blockIdx.x * KC + kc) * 8 * 4 + (col >> 4)) * 64 + ((kg << 4) | (col & 15));
+  auto planes = [&](const u32 (&x)[16], int j0) {
+    u32 o[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32 a = __builtin_amdgcn_perm(x[4 * g + 1], x[4 * g], 0x05010400u);
+      const u32 b = __builtin_amdgcn_perm(x[4 * g + 1], x[4 * g], 0x07030602u);
+      const u32 c = __builtin_amdgcn_perm(x[4 * g + 3], x[4 * g + 2], 0x05010400u);
+      const u32 d = __builtin_amdgcn_perm(x[4 * g + 3], x[4 * g + 2], 0x07030602u);
+      o[0][g] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+      o[1][g] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+      o[2][g] = __builtin_amdgcn_perm(d, b, 0x05040100u);
+      o[3][g] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[(size_t)(j0 + j) * 4 * 64] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+  };
+  planes(lo, 0);
+  planes(hi, 4);
+}
+
+// one step of x mod (2^b - c) on a 128-bit value: (x mod 2^b) + (x >> b) * c, for 32 < b < 64 and x < 2^(64+b)
+__device__ __forceinline__ void fold128(u64 &hi, u64 &lo, u32 c, u32 b) {
+  const u64 h = (hi << (64 - b)) | (lo >> b), l = lo & ((u64(1) << b) - 1);
+  const u64 t0 = mad32(lo32(h), c, l);    // below 2^64: l < 2^62 and the product < 2^63
+  const u64 t1 = mul32(hi32(h), c);
+  lo = t0 + (t1 << 32);
+  hi = (t1 >> 32) + (lo < t0);
+}
+
+// A workgroup of 8 waves owns 128 filters x 64 columns; wave (wm, wn) owns filters 64 wm .. +63 (4 tiles of 16)
+// and columns 16 wn .. +15.  Per 64-channel step the 32 KiB of column digits and 16/24 KiB of weight digits are
+// copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging registers; both images are
+// already in fragment order, lane l reads unit l, conflict free) into one of two buffers while the products of
+// earlier steps run: three buffers, two steps in flight, one raw barrier per step (two buffers and one step in
+// flight when the weights need a third digit).  Ten i32 accumulator tiles per filter tile, one per power of
+// 256, started at 2^28 so that the sums stay positive.
+// Workgroups are dealt to the XCDs round robin by the dispatcher; the index arithmetic below gives each XCD
+// whole column tiles, all of whose filter tiles then stream the same digits out of that XCD's L2.
+constexpr int kPwLdsBytes = 3 * (2048 + 1024) * 16;   // 144 KiB: three buffers of 2 weight digits (two of 3 fit too)
+__global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ u8, const uint4 *__restrict__ w8,
+                                                      const u32 *__restrict__ flag, const int *__restrict__ live,
+                                                      u64 *__restrict__ acc, int M, int MT, int KC, int n_live,
+                                                      size_t S, int logN, const DevMod *__restrict__ mods) {
+  extern __shared__ uint4 pw_lds[];
+  const u32 fl = *flag;
+  if (fl & 1u) return;
+  const int nA = (fl & 2u) ? 3 : 2;
+  const int seq = blockIdx.x >> 3, slot = (seq / MT) * 8 + (blockIdx.x & 7), mt = seq % MT;
+  if (slot >= n_live) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+  const int N = 1 << logN;
+  const size_t cols = S * 4 * N, c0 = (size_t)live[slot] * 64;
+  const size_t col = c0 + wn * 16 + (lane & 15);
+  const int mrow = mt * 128 + wm * 64 + (lane >> 4) * 4;   // + 16*ms + r
+  const int l = (int)((c0 >> logN) & 1);
+  const uint4 *__restrict__ gB = u8 + (size_t)slot * KC * 2048 + lane;
+  const uint4 *__restrict__ gA = w8 + (size_t)mt * KC * 1536 + lane;
+  const int stride = 2048 + 512 * nA, nbuf = nA == 2 ? 3 : 2;   // uint4 per buffer: column digits, weight digits
+  const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) void *)pw_lds;
+  // One 1 KiB copy global -> LDS: lane l's 16 bytes land at dst + 16 l.  Inline asm so that hipcc neither counts
+  // the copy nor drains it before the next LDS read; the waits below count them.
+  auto glds16 = [&](const uint4 *src, u32 dst_unit) {
+    u32 keep;
+    const u32 dst = __builtin_amdgcn_readfirstlane(lds0 + dst_unit * 1024);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+  };
+  auto stage = [&](int kc, int buf) {   // this wave's share: 4 KiB of column digits, 1 KiB per weight digit
+    const u32 unit0 = (u32)(buf * stride) / 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) glds16(gB + (size_t)kc * 2048 + (wave * 4 + r) * 64, unit0 + wave * 4 + r);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      if (a < nA) glds16(gA + (size_t)kc * 1536 + (a * 8 + wave) * 64, unit0 + 32 + a * 8 + wave);
+  };
+  v4i sum[4][10];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int d = 0; d < 10; ++d) sum[ms][d] = v4i{1 << 28, 1 << 28, 1 << 28, 1 << 28};
+  stage(0, 0);
+  if (nbuf == 3 && KC > 1) stage(1, 1);
+  int cur = 0;                     // buffer of step kc
+  for (int kc = 0; kc < KC; ++kc) {
+    // step kc has landed (this wave's copies; the barrier covers the others'), a later step may stay in flight;
+    // past the barrier every wave is done with the buffer of step kc - 1, which the new copies overwrite.
+    // A raw barrier: __syncthreads() would drain the copies in flight.
+    if (nbuf == 3 && kc + 1 < KC)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 4 + 2 copies per wave and step
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int ahead = kc + nbuf - 1;
+    if (ahead < KC) {
+      int buf = cur + nbuf - 1;
+      if (buf >= nbuf) buf -= nbuf;
+      stage(ahead, buf);
+    }
+    const uint4 *ldsB = pw_lds + cur * stride, *ldsA = ldsB + 2048;
+    cur = cur + 1 == nbuf ? 0 : cur + 1;
+    v4i b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint4 t = ldsB[(j * 4 + wn) * 64 + lane];
+      b[j] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+    }
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (a < nA) {
+          const uint4 t = ldsA[(a * 8 + wm * 4 + ms) * 64 + lane];
+          const v4i av = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            sum[ms][a + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], sum[ms][a + j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // value = sum_d (sum[d] - 2^28) 256^d, signed, below 2^100 in magnitude.  Assemble the biased digits into
+  // 128 bits, add k*q - bias (k*q in [2^101, 2^102)) to land on a non-negative representative below 2^103,
+  // then reduce: two folds of q = 2^b - c where the modulus has that shape, else Barrett.
+  const DevMod q = mods[l];
+  const u32 qbits = 64 - (u32)__builtin_clzll(q.q), sh = 102 - qbits;   // q << sh in [2^101, 2^102)
+  const u64 kq_lo = q.q << sh, kq_hi = q.q >> (64 - sh);
+  const u64 off_lo = kq_lo - 0x1010101010000000ull, off_hi = kq_hi - 0x1010101010ull - (kq_lo < 0x1010101010000000ull);
+  const u32 fb = q.fold_shift + 32, fc = q.fold_c;
+  // fold bounds: x < 2^103 -> x1 < 2^b + 2^(103-b) c (bits1 bits) -> x2 < 2^b + (x1 >> b) c (bits2 bits, must fit a word)
+  bool folds = fc != 0 && fb >= 40 && fb <= 62;
+  if (folds) {
+    const u32 cb = 32 - (u32)__builtin_clz(fc);
+    const u32 bits1 = max(fb, 103 - fb + cb) + 1;
+    const u32 bits2 = max(fb, bits1 - fb + cb) + 1;
+    folds = bits1 <= 64 + fb && bits2 <= 64;
+  }
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mrow + 16 * ms + r;
+      u64 lo = (u32)sum[ms][3][r], mid = (u32)sum[ms][7][r], top = (u32)sum[ms][9][r];
+#pragma unroll
+      for (int d = 2; d >= 0; --d) lo = (lo << 8) + (u32)sum[ms][d][r], mid = (mid << 8) + (u32)sum[ms][4 + d][r];
+      top = (top << 8) + (u32)sum[ms][8][r];
+      u64 xlo = lo + (mid << 32);
+      u64 xhi = (mid >> 32) + top + (xlo < lo);
+      xlo += off_lo;
+      xhi += off_hi + (xlo < off_lo);
+      u64 v;
+      if (folds) {
+        fold128(xhi, xlo, fc, fb);
+        fold128(xhi, xlo, fc, fb);
+        v = csub(fold_mod(xlo, fc, q.fold_shift, q.fold_mask), q.q);
+      } else {
+        v = reduce128_wide(xhi, xlo, q);
+      }
+      if (m < M) acc[(size_t)m * cols + col] = v;
+    }
+}
+
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 struct PwSizes {
-  int M, Mpad, C, Cpad, wc;
+  int M, Mpad, Mpad128, C, Cpad, Cpad64, wc;
+  size_t w8_bytes() const { return (size_t)Mpad128 * Cpad64 * 3; }
 };
+static bool pw_use_mfma() {  // MMH_CONV_PW_MFMA=0 keeps the fast form on the vector ALU (A/B measurements)
+  const char *e = getenv("MMH_CONV_PW_MFMA");
+  return !(e && e[0] == '0');
+}
 static PwSizes pw_sizes(const mmh_conv_plan *p) {
   PwSizes z;
   z.M = (int)p->meta.n_filters, z.Mpad = (z.M + 63) / 64 * 64, z.C = (int)p->f.c, z.wc = (int)p->split.win_c;
   z.Cpad = (z.C + kPwChunk - 1) / kPwChunk * kPwChunk;
+  z.Mpad128 = (z.M + 127) / 128 * 128, z.Cpad64 = (z.C + 63) / 64 * 64;
   return z;
 }
 // weights of the 1x1 route from the raw filters or from encoded plaintexts; flag must be zeroed first
 static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, const u64 *d_filter_pts, u32 *wp,
-                             u64 *wl, u32 *flag, hipStream_t s) {
+                             u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s) {
   const mmh_ctx *ctx = p->ctx;
   const PwSizes z = pw_sizes(p);
   const long plane = p->split.win_h * p->split.win_w;
   MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
   if (d_filters_raw)
-    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)z.Cpad * z.Mpad)), dim3(256), 0, s, d_filters_raw,
-                       wp, wl, flag, z.M, z.Mpad, z.C, z.Cpad, z.wc, (int)p->n_cslices, ctx->logN, p->filt_origin,
-                       plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
+                       d_filters_raw, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, z.wc,
+                       (int)p->n_cslices, ctx->logN, p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0],
+                       ctx->q[1]);
   else
-    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)z.Cpad * z.Mpad)), dim3(256), 0, s, d_filter_pts,
-                       wp, wl, flag, z.M, z.Mpad, z.C, z.Cpad, z.wc, (int)p->n_cslices, ctx->logN, p->filt_origin,
-                       plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
+                       d_filter_pts, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, z.wc,
+                       (int)p->n_cslices, ctx->logN, p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0],
+                       ctx->q[1]);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
-static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const u32 *flag,
-                             u64 *acc, hipStream_t s, int form = -1) {
+static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
+                             const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const PwSizes z = pw_sizes(p);
@@ -403,32 +642,54 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     hipLaunchKernelGGL(kern, dim3((unsigned)(cols / 64), (unsigned)(z.Mpad / tf)), dim3(256), 0, s, image, wp, wl, flag,
                        p->d_keep, p->d_pw_chan, acc, z.M, z.Mpad, z.Cpad, S, ctx->logN, ctx->d_mods);
   };
-  // the device-side flag picks the instantiation that runs; a caller that already knows it skips the other
+  // the device-side flag picks the kernel that runs; a caller that already knows the form skips the other
+  // (the epilogue's k*q offset needs moduli of at least 40 bits; SEAL's are 49 and 60)
+  const bool mfma = pw_use_mfma() && (ctx->q[0] >> 39) != 0 && (ctx->q[1] >> 39) != 0;
+  if (mfma && form != 1) {
+    // fast form on the matrix cores: byte digits of the rotated columns once, then the i8 products
+    const int KC = z.Cpad64 / 64, MT = z.Mpad128 / 128, n_live = (int)p->pw_live_tiles;
+    void *u8 = nullptr;
+    if (scratch_alloc(&u8, (size_t)n_live * KC * 32768, s) != hipSuccess) {
+      set_error("pointwise_product: allocation failed");
+      return MMH_ERR_MEMORY;
+    }
+    if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
+    hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_live,
+                       (uint4 *)u8, flag, z.C, KC, z.wc, (int)p->filt_origin, (int)(p->split.win_h * p->split.win_w), S,
+                       ctx->logN);
+    hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
+                       (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
+                       ctx->logN, ctx->d_mods);
+    (void)scratch_free(u8, s);
+  }
   if (wide) {
-    if (form != 1) launch(pw_gemm_kernel<true, 16>, 64);
+    if (!mfma && form != 1) launch(pw_gemm_kernel<true, 16>, 64);
     if (form != 0) launch(pw_gemm_kernel<false, 16>, 64);
   } else {
-    if (form != 1) launch(pw_gemm_kernel<true, 8>, 32);
+    if (!mfma && form != 1) launch(pw_gemm_kernel<true, 8>, 32);
     if (form != 0) launch(pw_gemm_kernel<false, 8>, 32);
   }
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
 static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_filters_raw,
-                         const u64 *d_filter_pts, u64 *acc, hipStream_t s) {
+                         const u64 *d_filter_pts, u64 *acc, hipStream_t s, bool fill_dead) {
   const PwSizes z = pw_sizes(p);
-  void *wp = nullptr, *wl = nullptr, *flag = nullptr;
+  void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *flag = nullptr;
   int rc = MMH_OK;
   auto grab = [&](void **b, size_t bytes) {
     if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
   grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
   grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
+  grab(&w8, z.w8_bytes());
   grab(&flag, 4);
   if (rc) set_error("pointwise_mac: allocation failed");
-  if (!rc) rc = pointwise_weights(p, d_filters_raw, d_filter_pts, (u32 *)wp, (u64 *)wl, (u32 *)flag, s);
-  if (!rc) rc = pointwise_product(p, image, (const u32 *)wp, (const u64 *)wl, (const u32 *)flag, acc, s);
-  for (void *b : {wp, wl, flag})
+  if (!rc) rc = pointwise_weights(p, d_filters_raw, d_filter_pts, (u32 *)wp, (u64 *)wl, (uint8_t *)w8, (u32 *)flag, s);
+  if (!rc)
+    rc = pointwise_product(p, image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8, (const u32 *)flag, acc, s,
+                           fill_dead);
+  for (void *b : {wp, wl, w8, flag})
     if (b) (void)scratch_free(b, s);
   return rc;
 }
@@ -560,10 +821,27 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
   p->pointwise = f.h == 1 && f.w == 1 && sp.win_c <= kPwMaxWc && in.c <= 4096 && ctx->L == 2 &&
                  !(pw_env && pw_env[0] == '0');
   if (p->pointwise) {
-    std::vector<PwChannel> chan((size_t)(in.c + kPwChunk - 1) / kPwChunk * kPwChunk, PwChannel{0, 0});
+    std::vector<PwChannel> chan((size_t)(in.c + 63) / 64 * 64, PwChannel{0, 0});
     for (long ch = 0; ch < in.c; ++ch)
       chan[ch] = PwChannel{(int)(ch / sp.win_c), (int)(p->filt_origin - (ch % sp.win_c) * sp.win_h * sp.win_w)};
-    if ((rc = upload_vec(p, chan, &p->d_pw_chan))) {
+    // 64-column tiles (spatial window, c0/c1, limb, 64 coefficients) the product has to compute: all of c1, of
+    // c0 those holding a kept coefficient
+    std::vector<int> live_tiles;
+    for (size_t b = 0; b < p->n_spatial * 4 * (size_t)N / 64; ++b) {
+      const size_t sp_i = (b * 64) / (4 * (size_t)N), pl = ((b * 64) / (size_t)N) & 3, i0 = (b * 64) % (size_t)N;
+      bool live = pl >= 2;
+      for (size_t i = 0; i < 64 && !live; ++i) live = keep[sp_i * N + i0 + i] != 0;
+      if (live) live_tiles.push_back((int)b);
+    }
+    p->pw_live_tiles = live_tiles.size();
+    // the product's two LDS buffers exceed the static 64 KiB: opt in (per device; plans are made on the context's)
+    if (hipFuncSetAttribute((const void *)pw_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) !=
+        hipSuccess) {
+      set_error("mmh_conv_plan_create: hipFuncSetAttribute failed");
+      mmh_conv_plan_destroy(p);
+      return MMH_ERR_INTERNAL;
+    }
+    if ((rc = upload_vec(p, chan, &p->d_pw_chan)) || (rc = upload_vec(p, live_tiles, &p->d_pw_live))) {
       mmh_conv_plan_destroy(p);
       return rc;
     }
@@ -680,10 +958,10 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
   if (!rc && p->pointwise && prepared)
-    rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->flag, (u64 *)acc, s,
-                           prepared->form);
+    rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
+                           (u64 *)acc, s, exact, prepared->form);
   if (!rc && p->pointwise && !prepared)
-    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s);
+    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact);
   if (!rc && !p->pointwise && !prepared && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
@@ -751,7 +1029,7 @@ extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d
 
 extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {
   if (!f) return MMH_OK;
-  for (void *b : {(void *)f->f_ntt, (void *)f->wp, (void *)f->wl, (void *)f->flag})
+  for (void *b : {(void *)f->f_ntt, (void *)f->wp, (void *)f->wl, (void *)f->w8, (void *)f->flag})
     if (b) (void)hipFree(b);
   delete f;
   return MMH_OK;
@@ -774,14 +1052,15 @@ extern "C" int mmh_conv_filters_prepare(const mmh_conv_plan *p, const uint64_t *
     const PwSizes z = pw_sizes(p);
     own((void **)&f->wp, (size_t)z.Cpad * z.Mpad * 4);
     own((void **)&f->wl, (size_t)z.Cpad * z.Mpad * 16);
+    own((void **)&f->w8, z.w8_bytes());
     own((void **)&f->flag, 4);
-    if (!rc) rc = pointwise_weights(p, d_filters, nullptr, f->wp, f->wl, f->flag, s);
+    if (!rc) rc = pointwise_weights(p, d_filters, nullptr, f->wp, f->wl, f->w8, f->flag, s);
     if (!rc) {  // model-load time: one synchronous read of which weight form the layer needs
       u32 general = 0;
       if (hipMemcpyAsync(&general, f->flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
           hipStreamSynchronize(s) != hipSuccess)
         rc = MMH_ERR_INTERNAL;
-      f->form = general ? 1 : 0;
+      f->form = (general & 1u) ? 1 : 0;
     }
   } else {
     const size_t M = (size_t)p->meta.n_filters, Cs = p->n_cslices;
