@@ -26,7 +26,7 @@ struct ImgWindow {
   int nc, nh, nw;          // window size before mocking
   int lo_y, hi_y, lo_x, hi_x;
 };
-struct PwChannel { int row, e; };  // 1x1 route: channel -> input ciphertext row (channel slice) and rotation
+struct PwChannel { int row, e; };  // direct route: filter tap -> input ciphertext row (channel slice) and rotation
 }  // namespace mmh
 
 struct mmh_conv_plan {
@@ -49,7 +49,9 @@ struct mmh_conv_plan {
   int *d_share_dst = nullptr;            // [n_spatial][N] offset of a target coefficient in the result plane, else -1
   // 1x1 filters with few channels per polynomial: multiply-accumulate as a mod-q matrix product over
   // channels (pointwise_mac below) instead of transforming M*Cs sparse filter polynomials
-  bool pointwise = false;
+  bool direct_capable = false;           // tables below are built
+  bool direct_fresh = false;             // the direct product is the cheaper route when the filters arrive with the call
+  bool direct_prepared = false;          // ... and when they were prepared (no filter transforms on the other route)
   mmh::PwChannel *d_pw_chan = nullptr;   // [C rounded up to 64]: input row (channel slice) and rotation of a channel
   int *d_pw_live = nullptr;              // [pw_live_tiles] the 64-column tiles the product computes (index = column / 64)
   size_t pw_live_tiles = 0;
@@ -185,16 +187,16 @@ template <bool FROM_PTS>
 __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__ src, u32 *__restrict__ wp,
                                                          u64 *__restrict__ wl, uint8_t *__restrict__ w8,
                                                          u32 *__restrict__ flag, int M, int Mpad, int Mpad128, int C,
-                                                         int Cpad, int Cpad64, int wc, int n_cslices, int logN,
-                                                         long origin, long plane, ModC t, u64 thr, u64 q0, u64 q1) {
+                                                         int Cpad, int Cpad64, const PwChannel *__restrict__ chan,
+                                                         int n_cslices, int logN, ModC t, u64 thr, u64 q0, u64 q1) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (size_t)Cpad64 * Mpad128) return;
   const int m = (int)(gid % Mpad128), ch = (int)(gid / Mpad128);
   u64 v = 0;  // filters and channels beyond the real ones weigh nothing
   if (m < M && ch < C) {
     if (FROM_PTS) {
-      const int sl = ch / wc, c = ch % wc;
-      v = src[(((size_t)m * n_cslices + sl) << logN) + (origin - c * plane)];
+      const PwChannel pc = chan[ch];   // the tap's coefficient in the polynomial of its channel slice
+      v = src[(((size_t)m * n_cslices + pc.row) << logN) + pc.e];
     } else {
       v = red_t(src[(size_t)m * C + ch], t);
     }
@@ -399,9 +401,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr u64 kDigitBias = 0x0080808080808080ull;
 
 __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ image,
+                                                        const PwChannel *__restrict__ chan,
                                                         const int *__restrict__ live, uint4 *__restrict__ u8,
-                                                        const u32 *__restrict__ flag, int C, int KC, int wc,
-                                                        int origin, int plane, size_t S, int logN) {
+                                                        const u32 *__restrict__ flag, int KC, size_t S, int logN) {
   if (*flag & 1u) return;
   const size_t c0 = (size_t)live[blockIdx.x] * 64;   // first column of the tile: (sp, c0/c1, limb, i)
   const int kc = blockIdx.y, N = 1 << logN;
@@ -412,15 +414,13 @@ __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ 
   const u64 *__restrict__ base = image + ((sp * 4 + pl) << logN);
   const size_t row_step = S * 4 * N;
   u32 lo[16], hi[16];
+  PwChannel pc[16];   // padding taps read row 0 against zero weights
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pc[k] = chan[kc * 64 + kg * 16 + k];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const int ch = kc * 64 + kg * 16 + k;
-    u64 v = 0;
-    if (ch < C) {
-      const int row = ch / wc, e = origin - (ch - row * wc) * plane;
-      v = base[(size_t)row * row_step + ((i - e) & (N - 1))];
-      if (i < e) v = 0 - v;  // X^N = -1: wrapped coefficients enter negated, as plain negative integers
-    }
+    u64 v = base[(size_t)pc[k].row * row_step + ((i - pc[k].e) & (N - 1))];
+    if (i < pc[k].e) v = 0 - v;  // X^N = -1: wrapped coefficients enter negated, as plain negative integers
     const u64 d = (v + kDigitBias) ^ kDigitBias;
     lo[k] = (u32)d, hi[k] = (u32)(d >> 32);
   }
@@ -604,7 +604,7 @@ static bool pw_use_mfma() {  // MMH_CONV_PW_MFMA=0 keeps the fast form on the ve
 }
 static PwSizes pw_sizes(const mmh_conv_plan *p) {
   PwSizes z;
-  z.M = (int)p->meta.n_filters, z.Mpad = (z.M + 63) / 64 * 64, z.C = (int)p->f.c, z.wc = (int)p->split.win_c;
+  z.M = (int)p->meta.n_filters, z.Mpad = (z.M + 63) / 64 * 64, z.C = (int)p->f.count(), z.wc = (int)p->split.win_c;
   z.Cpad = (z.C + kPwChunk - 1) / kPwChunk * kPwChunk;
   z.Mpad128 = (z.M + 127) / 128 * 128, z.Cpad64 = (z.C + 63) / 64 * 64;
   return z;
@@ -614,18 +614,15 @@ static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, c
                              u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s) {
   const mmh_ctx *ctx = p->ctx;
   const PwSizes z = pw_sizes(p);
-  const long plane = p->split.win_h * p->split.win_w;
   MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
   if (d_filters_raw)
     hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
-                       d_filters_raw, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, z.wc,
-                       (int)p->n_cslices, ctx->logN, p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0],
-                       ctx->q[1]);
+                       d_filters_raw, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, p->d_pw_chan,
+                       (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
   else
     hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
-                       d_filter_pts, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, z.wc,
-                       (int)p->n_cslices, ctx->logN, p->filt_origin, plane, ctx->bfv.t, ctx->bfv.thr, ctx->q[0],
-                       ctx->q[1]);
+                       d_filter_pts, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, p->d_pw_chan,
+                       (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
@@ -654,9 +651,8 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
       return MMH_ERR_MEMORY;
     }
     if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
-    hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_live,
-                       (uint4 *)u8, flag, z.C, KC, z.wc, (int)p->filt_origin, (int)(p->split.win_h * p->split.win_w), S,
-                       ctx->logN);
+    hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_chan,
+                       p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN);
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
                        ctx->logN, ctx->d_mods);
@@ -815,15 +811,20 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
   p->n_targets = coef.size();
   std::vector<int> share_dst(p->n_spatial * (size_t)N, -1);
   for (size_t g = 0; g < coef.size(); ++g) share_dst[(size_t)slice[g] * N + coef[g]] = (int)dst[g];
-  // 1x1 filters, few channels per polynomial: channel-wise matrix product (MMH_CONV_POINTWISE=0 keeps
-  // the transform route for A/B measurements)
-  const char *pw_env = getenv("MMH_CONV_POINTWISE");
-  p->pointwise = f.h == 1 && f.w == 1 && sp.win_c <= kPwMaxWc && in.c <= 4096 && ctx->L == 2 &&
-                 !(pw_env && pw_env[0] == '0');
-  if (p->pointwise) {
-    std::vector<PwChannel> chan((size_t)(in.c + 63) / 64 * 64, PwChannel{0, 0});
-    for (long ch = 0; ch < in.c; ++ch)
-      chan[ch] = PwChannel{(int)(ch / sp.win_c), (int)(p->filt_origin - (ch % sp.win_c) * sp.win_h * sp.win_w)};
+  // Direct route (pointwise_mac): the layer as a mod-q matrix product over the filter taps instead of
+  // transforming M*Cs sparse filter polynomials.  Tap k = (c, r, col) of a filter multiplies the input
+  // polynomial of channel slice c / wc rotated by its coefficient index (EncodeFilter's, above).
+  const long taps = f.count();
+  // (at most 5120 taps: the i32 digit sums stay below 3 * taps * 2^14 < 2^28, the 64-bit ones of the vector form
+  // below 5120 * 2^51 < 2^64)
+  p->direct_capable = taps <= 5120 && ctx->L == 2;
+  if (p->direct_capable) {
+    std::vector<PwChannel> chan((size_t)(taps + 63) / 64 * 64, PwChannel{0, 0});
+    for (long k = 0; k < taps; ++k) {
+      const long c = k / (f.h * f.w), r = (k / f.w) % f.h, col = k % f.w;
+      chan[k] = PwChannel{(int)(c / sp.win_c),
+                          (int)(p->filt_origin - (c % sp.win_c) * sp.win_h * sp.win_w - r * sp.win_w - col)};
+    }
     // 64-column tiles (spatial window, c0/c1, limb, 64 coefficients) the product has to compute: all of c1, of
     // c0 those holding a kept coefficient
     std::vector<int> live_tiles;
@@ -845,6 +846,19 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
       mmh_conv_plan_destroy(p);
       return rc;
     }
+    // Which route is cheaper (microseconds, from the measured rates of DESIGN.md 5): the direct product costs
+    // 16 byte products per tap, filter and live column plus the digit image; the transform route two filter
+    // transforms (none when prepared) and S dyadic products per filter polynomial plus the transforms of the
+    // image and of the result.  MMH_CONV_POINTWISE=0 / 1 forces the transform / the direct route.
+    const double M_ = (double)meta->n_filters, Cs_ = (double)p->n_cslices, S_ = (double)p->n_spatial;
+    const double live_cols = 64.0 * (double)p->pw_live_tiles, kpad = (double)chan.size();
+    const double t_direct = std::ceil(M_ / 128) * 128 * kpad * live_cols * 16 / 0.8e9 + kpad * live_cols * 8 / 1.5e6;
+    const double t_rest = ((double)p->n_in * 4 + M_ * S_ * 4) / 54.0;
+    const double t_fresh = M_ * Cs_ * (2 + S_) / 54.0 + t_rest, t_prepared = M_ * Cs_ * S_ / 54.0 + t_rest;
+    const char *pw_env = getenv("MMH_CONV_POINTWISE");
+    const bool never = pw_env && pw_env[0] == '0', always = pw_env && pw_env[0] == '1';
+    p->direct_fresh = !never && (always || t_direct < t_fresh);
+    p->direct_prepared = !never && (always || t_direct < t_prepared);
   }
   if ((rc = upload_vec(p, wins, &p->d_windows)) || (rc = upload_vec(p, coef, &p->d_tgt_coef)) ||
       (rc = upload_vec(p, dst, &p->d_tgt_dst)) || (rc = upload_vec(p, slice, &p->d_tgt_slice)) ||
@@ -938,6 +952,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
   void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr, *mask_t = nullptr;
+  // the route: prepared filters carry the one they were prepared for
+  const bool direct = prepared ? prepared->w8 != nullptr : p->direct_fresh;
   int rc = MMH_OK;
   auto cleanup = [&]() {
     for (void *b : {image, acc, zero, f_ntt, mask_t})
@@ -948,33 +964,33 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   };
   grab(&image, p->n_in * 4 * N * 8);
   grab(&acc, p->n_out * 4 * N * 8);
-  if (!p->pointwise && !prepared) grab(&f_ntt, M * Cs * 2 * N * 8);
+  if (!direct && !prepared) grab(&f_ntt, M * Cs * 2 * N * 8);
   // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
   if (!rc && p->meta.is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
   if (!rc && !p->meta.is_shared_input &&
       hipMemcpyAsync(image, d_in_cts, p->n_in * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
     rc = MMH_ERR_INTERNAL;
-  if (!rc && !p->pointwise) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
+  if (!rc && !direct) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
-  if (!rc && p->pointwise && prepared)
+  if (!rc && direct && prepared)
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
                            (u64 *)acc, s, exact, prepared->form);
-  if (!rc && p->pointwise && !prepared)
+  if (!rc && direct && !prepared)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact);
-  if (!rc && !p->pointwise && !prepared && d_filters_raw)
+  if (!rc && !direct && !prepared && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
                              p->split.win_w, 2, s);
-  if (!rc && !p->pointwise && !prepared && !d_filters_raw)
+  if (!rc && !direct && !prepared && !d_filters_raw)
     rc = ntt_lift_dispatch(ctx, d_filter_pts, (u64 *)f_ntt, M * Cs, 2, s);
   // conv2DOneFilter :597-616 for every filter: out[m][i] = sum_c image[c*S + i] * filter[m][c]
-  if (!rc && !p->pointwise)
+  if (!rc && !direct)
     rc = mmh_dyadic_mac(ctx, 0, (const u64 *)image, p->n_in, filt_ntt, M * Cs, M, S, Cs, S, 1, Cs, 1, 0, (u64 *)acc, stream);
   if (!rc && !exact) {
     // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
-    rc = reshare_tail_approx(ctx, (u64 *)acc, !p->pointwise, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
+    rc = reshare_tail_approx(ctx, (u64 *)acc, !direct, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
                              d_out_cts, s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share);
   }
   if (exact) {
@@ -982,7 +998,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     // by sub_plain and the share is the mask itself (:225-272, :358-380)
     grab(&zero, p->n_out * 2 * N * 8);
     grab(&mask_t, p->n_out * N * 8);
-    if (!rc && !p->pointwise) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
+    if (!rc && !direct) rc = ntt_dispatch(ctx, true, (u64 *)acc, p->n_out * 2, 2, 0, s);
     if (!rc) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
     if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
     if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
@@ -1048,7 +1064,7 @@ extern "C" int mmh_conv_filters_prepare(const mmh_conv_plan *p, const uint64_t *
   auto own = [&](void **b, size_t bytes) {
     if (!rc && hipMalloc(b, bytes) != hipSuccess) rc = MMH_ERR_MEMORY;
   };
-  if (p->pointwise) {
+  if (p->direct_prepared) {
     const PwSizes z = pw_sizes(p);
     own((void **)&f->wp, (size_t)z.Cpad * z.Mpad * 4);
     own((void **)&f->wl, (size_t)z.Cpad * z.Mpad * 16);

@@ -74,9 +74,14 @@ def test_pointwise_route_general_weights(mm, wbound):
         assert np.array_equal(host(got[0]), ref_out) and np.array_equal(host(got[1]), ref_share)
 
 
+# the server multiplies either through filter transforms or through the direct tap-wise matrix product; the
+# plan's cost model picks one ("model"), MMH_CONV_POINTWISE forces the transform ("0") or the direct route ("1")
+@pytest.mark.parametrize("route", ["model", "0", "1"])
 @pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", CASES)
-def test_conv_layer_bit_exact(mm, ishape, fhw, M, same, stride, shared):
+def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, shared, route):
     from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    if route != "model":
+        monkeypatch.setenv("MMH_CONV_POINTWISE", route)   # read when the plan is made
     o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
     fshape = (ishape[0],) + tuple(fhw)
     cv = ConvOracle(o, ishape, fshape, M, same, stride, shared)
