@@ -10,6 +10,8 @@ int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys,
                  int mod_base, hipStream_t s);
 int ntt_signed_dispatch(const mmh_ctx *ctx, const int64_t *d_src, u64 *d_out, size_t n_polys, int limbs,
                         hipStream_t s);
+int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, u64 *d_out, size_t n,
+                             int limbs, hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
 
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void truncate_kernel(u64 *__restrict__ cts, si
 // :392-441, :108-140): out = truncate(mod_switch(acc) + zero + (0, e1) - (mask, 0)) with the unused
 // coefficients of c0 cleared.  acc [n][2][2][N] coefficient form at the first level; zero [n][2][N] the
 // noiseless pk-encryption of zero at the last level; mask [n][N] mod q0; e1 signed.
+// Two neighbouring coefficients per thread: 16-byte loads and stores on every stream.
 __global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ zero,
                                                              const int64_t *__restrict__ e1,
                                                              const u64 *__restrict__ mask, u64 *__restrict__ out,
@@ -351,36 +354,58 @@ __global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restri
                                                              size_t keep_period, const DevMod *__restrict__ mods,
                                                              const int *__restrict__ share_dst, size_t share_plane,
                                                              u64 *__restrict__ share_out, BfvConsts b) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n][N]
+  const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;  // over [n][N], an even coefficient
   if (idx >= total) return;
   const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
   const DevMod &q0 = mods[0];
+  typedef ulonglong2 v2;
+  auto ld2 = [](const u64 *ptr) { return *reinterpret_cast<const v2 *>(ptr); };
+  const size_t kp = ((k % keep_period) << logN) + i;
+  bool kept[2] = {true, true};
+  if (keep) {
+    const uchar2 kk = *reinterpret_cast<const uchar2 *>(keep + kp);
+    kept[0] = kk.x != 0, kept[1] = kk.y != 0;
+  }
+  const bool any_kept = kept[0] || kept[1];
+  v2 m = {0, 0};
+  if (any_kept || share_dst) m = ld2(mask + idx);
   if (share_dst) {  // the other party's share: scale-and-round of the mask at the target coefficients
-    const int dst = share_dst[((k % keep_period) << logN) + i];
-    if (dst >= 0) {
-      const u64 x[2] = {mask[idx], 0};
-      share_out[(k / keep_period) * share_plane + dst] = behz_round(x, b, b.lv[1], mods);
+    const int2 dst = *reinterpret_cast<const int2 *>(share_dst + kp);
+    if (dst.x >= 0) {
+      const u64 x[2] = {m.x, 0};
+      share_out[(k / keep_period) * share_plane + dst.x] = behz_round(x, b, b.lv[1], mods);
+    }
+    if (dst.y >= 0) {
+      const u64 x[2] = {m.y, 0};
+      share_out[(k / keep_period) * share_plane + dst.y] = behz_round(x, b, b.lv[1], mods);
     }
   }
   const u64 q1 = mods[1].q, half = q1 >> 1, half0 = reduce64(half, q0);
+  auto switched = [&](u64 a0, u64 a1, u64 z) {  // divide_and_round_q_last, then the encryption of zero
+    const u64 last = csub(a1 + half, q1);
+    const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
+    return add_mod(mul_mod(sub_mod(a0, tmp, q0.q), inv_qlast, q0), z, q0.q);
+  };
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const size_t p = k * 2 + j;
-    if (j == 0 && keep && !keep[((k % keep_period) << logN) + i]) {  // removed coefficient: nothing of it is read
-      out[(p << logN) + i] = 0;
-      continue;
+    v2 r = {0, 0};
+    if (j == 1 || any_kept) {  // of removed c0 coefficients nothing is read
+      const v2 a0 = ld2(acc + ((p * 2) << logN) + i), a1 = ld2(acc + ((p * 2 + 1) << logN) + i);
+      const v2 z = ld2(zero + (p << logN) + i);
+      r.x = switched(a0.x, a1.x, z.x), r.y = switched(a0.y, a1.y, z.y);
+      if (j == 1) {
+        if (e1) {
+          const longlong2 e = *reinterpret_cast<const longlong2 *>(e1 + idx);
+          r.x = add_mod(r.x, signed_to_mod(e.x, q0.q), q0.q), r.y = add_mod(r.y, signed_to_mod(e.y, q0.q), q0.q);
+        }
+        r.x &= mask1, r.y &= mask1;
+      } else {
+        r.x = kept[0] ? sub_mod(r.x, m.x, q0.q) & mask0 : 0;
+        r.y = kept[1] ? sub_mod(r.y, m.y, q0.q) & mask0 : 0;
+      }
     }
-    u64 last = csub(acc[((p * 2 + 1) << logN) + i] + half, q1);          // divide_and_round_q_last
-    const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
-    u64 v = mul_mod(sub_mod(acc[((p * 2) << logN) + i], tmp, q0.q), inv_qlast, q0);
-    v = add_mod(v, zero[(p << logN) + i], q0.q);
-    if (j == 1) {
-      if (e1) v = add_mod(v, signed_to_mod(e1[idx], q0.q), q0.q);
-      v &= mask1;
-    } else {
-      v = sub_mod(v, mask[idx], q0.q) & mask0;
-    }
-    out[(p << logN) + i] = v;
+    *reinterpret_cast<v2 *>(out + (p << logN) + i) = r;
   }
 }
 
@@ -670,8 +695,8 @@ extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t
 // addRandomMask + truncate_for_decryption + removeUnusedCoeffs of the shipped USE_APPROX_RESHARE build
 // (hom_conv2d_ss.cc:761-788, :698-703, :800-851; hom_fc_ss.cc:473-561) on n accumulated ciphertexts:
 // d_acc [n][2][2][N] at the first level, in NTT or coefficient form (consumed), d_out [n][2][N] at the last.
-// Five launches: inverse NTT of acc, forward NTT of u straight from the signed samples, pk product,
-// inverse NTT, and one pass that mod-switches, adds the encryption of zero and e1, subtracts the mask,
+// Four launches: inverse NTT of acc, forward NTT of u straight from the signed samples, inverse NTT of
+// its products with the key (formed while loading), and one pass that mod-switches, adds the encryption of zero and e1, subtracts the mask,
 // truncates, clears the unused coefficients and (d_share_dst [keep_period][N]: target index or -1) scatters
 // the mask's scale-and-round into the share tensor d_share_out [n / keep_period][share_plane].  Same bits as the step-by-step entry points.
 namespace mmh {
@@ -687,9 +712,8 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   MMH_HIP(zero.alloc(n * 2 * N * 8));
   if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
   CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
-  LAUNCH(mul_pk_kernel, n * N, s, u.as<u64>(), d_pk_ntt_last, zero.as<u64>(), n * N, ctx->logN, 1, ctx->d_mods);
-  CHECK_RC(ntt_dispatch(ctx, true, zero.as<u64>(), n * 2, 1, 0, s));
-  LAUNCH(reshare_finish_kernel, n * N, s, d_acc, zero.as<u64>(), d_e1, d_mask, d_out, n * N, ctx->logN,
+  CHECK_RC(ntt_inv_product_dispatch(ctx, u.as<u64>(), d_pk_ntt_last, zero.as<u64>(), n, 1, s));
+  LAUNCH(reshare_finish_kernel, n * N / 2, s, d_acc, zero.as<u64>(), d_e1, d_mask, d_out, n * N, ctx->logN,
          ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep, keep_period ? keep_period : 1,
          ctx->d_mods, d_share_dst, share_plane, d_share_out, ctx->bfv);
   return MMH_OK;

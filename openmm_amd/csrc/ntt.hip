@@ -217,6 +217,7 @@ __device__ __forceinline__ void inv_radix_f64(double (&x)[1 << R], const double 
 enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3 };
 struct NttSource {
   const u64 *p;
+  const u64 *p2;                   // inverse transform of a product: the key pair [2][limbs][N] (p = [n][limbs][N])
   u64 t, thr;                      // plain modulus and the lift threshold (t + 1) / 2
   u64 t_bhi, t_blo;                // Barrett constants of t (SRC_FILTER reduces the raw weights)
   int C, taps, wc, n_cslices;      // channels, fh*fw, channels per slice, slices per filter
@@ -439,11 +440,13 @@ __device__ __forceinline__ void ntt_inv_f64(u64 *__restrict__ a, const DevMod &M
   }
 }
 
-template <int LOGN, bool FOLD>
+// PROD: polynomial (k, j, l) of the output is the inverse transform of src.p[k][l] (.) src.p2[j][l], the dyadic
+// product formed while loading (encrypt_zero's u * pk_j without a pass of its own); else in place.
+template <int LOGN, bool FOLD, bool PROD = false>
 __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
-                                                      int limbs, int mod_base, NttSource) {
+                                                      int limbs, int mod_base, NttSource src) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
@@ -451,13 +454,28 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset + N;
   u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
 
-  const ulonglong2 *__restrict__ in = reinterpret_cast<const ulonglong2 *>(a);
+  if (PROD) {
+    const size_t kj = blockIdx.x / limbs, l = blockIdx.x % limbs;
+    const ulonglong2 *__restrict__ in =
+        reinterpret_cast<const ulonglong2 *>(src.p + (((kj >> 1) * limbs + l) << LOGN));
+    const ulonglong2 *__restrict__ key =
+        reinterpret_cast<const ulonglong2 *>(src.p2 + (((kj & 1) * limbs + l) << LOGN));
 #pragma unroll
-  for (int k = 0; k < N / 512; ++k) {
-    const int j = 2 * (k * 256 + t);
-    const ulonglong2 v = in[k * 256 + t];
-    lds[pad(j)] = v.x;
-    lds[pad(j) + 1] = v.y;
+    for (int k = 0; k < N / 512; ++k) {
+      const int j = 2 * (k * 256 + t);
+      const ulonglong2 v = in[k * 256 + t], w = key[k * 256 + t];
+      lds[pad(j)] = mul_mod(v.x, w.x, M);
+      lds[pad(j) + 1] = mul_mod(v.y, w.y, M);
+    }
+  } else {
+    const ulonglong2 *__restrict__ in = reinterpret_cast<const ulonglong2 *>(a);
+#pragma unroll
+    for (int k = 0; k < N / 512; ++k) {
+      const int j = 2 * (k * 256 + t);
+      const ulonglong2 v = in[k * 256 + t];
+      lds[pad(j)] = v.x;
+      lds[pad(j) + 1] = v.y;
+    }
   }
   __syncthreads();
   if (M.f64) {  // uniform over the workgroup
@@ -511,11 +529,12 @@ static constexpr size_t lds_bytes() {
   return ((size_t(1) << LOGN) + (size_t(1) << (LOGN - 4))) * sizeof(u64);
 }
 
-// mode: SRC_* for a forward transform, -1 for the inverse (in place)
+// mode: SRC_* for a forward transform, -1 for the inverse (in place), -2 for the inverse of a product
 template <int LOGN>
 static int launch(int mode, bool fold, u64 *d, const mmh_ctx *ctx, size_t blocks, int limbs, int mod_base,
                   const NttSource &src, hipStream_t s) {
-  auto kern = mode < 0 ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
+  auto kern = mode == -2 ? (fold ? ntt_inv_kernel<LOGN, true, true> : ntt_inv_kernel<LOGN, false, true>)
+              : mode < 0 ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
               : mode == SRC_PLAIN
                   ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_PLAIN> : ntt_fwd_kernel<LOGN, false, SRC_PLAIN>)
               : mode == SRC_FILTER
@@ -576,6 +595,14 @@ int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, si
   src.C = C, src.taps = fh * fw, src.wc = wc, src.n_cslices = n_cslices;
   src.fw = fw, src.origin = (int)origin, src.plane = (int)plane, src.row = (int)row;
   return dispatch(ctx, SRC_FILTER, d_out, src, n_filters * (size_t)n_cslices, limbs, 0, s);
+}
+
+// out[k][j][l] = INTT_l(u_ntt[k][l] (.) key[j][l]) for j = 0, 1 and the first `limbs` moduli
+int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, u64 *d_out, size_t n,
+                             int limbs, hipStream_t s) {
+  NttSource src{};
+  src.p = d_u_ntt, src.p2 = d_key;
+  return dispatch(ctx, -2, d_out, src, n * 2, limbs, 0, s);
 }
 
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
