@@ -473,18 +473,20 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
                                                       u64 *__restrict__ acc, int M, int MT, int KC, int n_live,
                                                       size_t S, int logN, const DevMod *__restrict__ mods) {
   extern __shared__ uint4 pw_lds[];
-  const u32 fl = *flag;
-  if (fl & 1u) return;
-  const int nA = (fl & 2u) ? 3 : 2;
   const int seq = blockIdx.x >> 3, slot = (seq / MT) * 8 + (blockIdx.x & 7), mt = seq % MT;
   if (slot >= n_live) return;
+  const u32 fl = *flag;                 // both loads in flight together: a workgroup has the CU to itself, so every
+  const int tile = live[slot];          // dependent load at its start is exposed latency
+  if (fl & 1u) return;
+  const int nA = (fl & 2u) ? 3 : 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int N = 1 << logN;
-  const size_t cols = S * 4 * N, c0 = (size_t)live[slot] * 64;
+  const size_t cols = S * 4 * N, c0 = (size_t)tile * 64;
   const size_t col = c0 + wn * 16 + (lane & 15);
   const int mrow = mt * 128 + wm * 64 + (lane >> 4) * 4;   // + 16*ms + r
   const int l = (int)((c0 >> logN) & 1);
+  const DevMod q = mods[l];             // for the epilogue; loaded here so that its latency hides behind the products
   const uint4 *__restrict__ gB = u8 + (size_t)slot * KC * 2048 + lane;
   const uint4 *__restrict__ gA = w8 + (size_t)mt * KC * 1536 + lane;
   const int stride = 2048 + 512 * nA, nbuf = nA == 2 ? 3 : 2;   // uint4 per buffer: column digits, weight digits
@@ -557,7 +559,6 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
   // value = sum_d (sum[d] - 2^28) 256^d, signed, below 2^100 in magnitude.  Assemble the biased digits into
   // 128 bits, add k*q - bias (k*q in [2^101, 2^102)) to land on a non-negative representative below 2^103,
   // then reduce: two folds of q = 2^b - c where the modulus has that shape, else Barrett.
-  const DevMod q = mods[l];
   const u32 qbits = 64 - (u32)__builtin_clzll(q.q), sh = 102 - qbits;   // q << sh in [2^101, 2^102)
   const u64 kq_lo = q.q << sh, kq_hi = q.q >> (64 - sh);
   const u64 off_lo = kq_lo - 0x1010101010000000ull, off_hi = kq_hi - 0x1010101010ull - (kq_lo < 0x1010101010000000ull);
