@@ -141,7 +141,7 @@ def layer_legs(torch, openmm_amd, local):
     rand = (rnd(-1, 2, plan.n_out, N), rnd(-8, 9, plan.n_out, N), rnd(0, 1 << 62, plan.n_out, N) % ctx.q[0])
 
     def conv_layer():  # what CheetahLinear::conv2d runs on the server per layer (cheetah-api.cpp:417-445)
-        return srv.conv2DSSFromWeights(cts, srv.encodeImage(share, meta), filters, meta, rand)
+        return srv.conv2DSSFromTensors(cts, share, filters, meta, rand)
 
     out["homconv_resnet50_3x3_56x56x64_ms"] = ms(conv_layer)
     out["homconv_reference_schedule_ntts"] = 40960
@@ -249,9 +249,9 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
         rand = (rnd(-1, 2, n_out, N), rnd(-8, 9, n_out, N), rnd(0, 1 << 62, n_out, N) % ctx.q[0])
 
         def layer():
+            if sh is None:   # encodeImage + encodeFilters + conv2DSS in one device call
+                return srv.conv2DSSFromTensors(cts, share if shared else None, filters, meta, rand)
             s = srv.encodeImage(share, meta) if shared else None
-            if sh is None:
-                return srv.conv2DSSFromWeights(cts, s, filters, meta, rand)
             return sh.run(cts, s, filters, lambda k: tuple(r[:k] for r in rand))
 
         ms = wall_ms(layer)

@@ -92,6 +92,43 @@ __global__ __launch_bounds__(256) void encode_image_kernel(const u64 *__restrict
   polys[idx] = v;
 }
 
+// EncodeImageShare fused with add_plain (conv2DSS :655-671 straight from the share tensor): out = ct + Delta * m
+// with m the coefficient encode_image_kernel would have written; both polynomials of every ciphertext are
+// written, so no copy and no plaintext buffer is needed.  Also clears `n_words` flag words of the call.
+__global__ __launch_bounds__(256) void image_plus_share_kernel(const u64 *__restrict__ in, const u64 *__restrict__ img,
+                                                               u64 *__restrict__ out,
+                                                               const ImgWindow *__restrict__ wins, size_t n_in,
+                                                               int logN, int wc, int wh, int ww, int H, int W,
+                                                               int sub_h, int sub_w, BfvConsts b,
+                                                               const DevMod *__restrict__ mods,
+                                                               u32 *__restrict__ words, int n_words) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (size_t)n_words) words[idx] = 0;
+  if (idx >= (n_in << logN)) return;
+  const size_t k = idx >> logN;
+  const int i = (int)(idx & ((size_t(1) << logN) - 1));
+  u64 m = 0;
+  if (img && i < wc * wh * ww) {
+    const ImgWindow g = wins[k];
+    const int c = i / (wh * ww), y = (i / ww) % wh, x = i % ww;
+    if (c < g.nc && y >= g.lo_y && y + g.hi_y < g.nh && x >= g.lo_x && x + g.hi_x < g.nw) {
+      const size_t cc = c + g.c0, yy = (size_t)(y - g.lo_y + g.y0) * sub_h, xx = (size_t)(x - g.lo_x + g.x0) * sub_w;
+      m = red_t(img[(cc * H + yy) * W + xx], b.t);
+    }
+  }
+  const LevelConsts &c0 = b.lv[0];
+  const u64 fix = m ? scale_fix(m, b, c0) : 0;
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const DevMod &q = mods[l];
+    const size_t o0 = (((k * 2) * 2 + l) << logN) + i, o1 = (((k * 2 + 1) * 2 + l) << logN) + i;
+    u64 v = in[o0];
+    if (m) v = add_mod(v, scaled_plain(m, fix, c0.delta_mod_q[l], q), q.q);
+    out[o0] = v;
+    out[o1] = in[o1];
+  }
+}
+
 // EncodeFilter: scatter filter m, channel c, tap (r, col) to its reversed coefficient
 __global__ __launch_bounds__(256) void encode_filter_kernel(const u64 *__restrict__ filt, u64 *__restrict__ polys,
                                                             size_t total, int logN, int C, int fh, int fw, int wc,
@@ -623,10 +660,10 @@ static PwSizes pw_sizes(const mmh_conv_plan *p) {
 }
 // weights of the 1x1 route from the raw filters or from encoded plaintexts; flag must be zeroed first
 static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, const u64 *d_filter_pts, u32 *wp,
-                             u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s) {
+                             u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s, bool flag_is_clear = false) {
   const mmh_ctx *ctx = p->ctx;
   const PwSizes z = pw_sizes(p);
-  MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
+  if (!flag_is_clear) MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
   if (d_filters_raw)
     hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
                        d_filters_raw, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, p->d_pw_chan,
@@ -681,9 +718,9 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
   return MMH_OK;
 }
 static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_filters_raw,
-                         const u64 *d_filter_pts, u64 *acc, hipStream_t s, bool fill_dead) {
+                         const u64 *d_filter_pts, u64 *acc, hipStream_t s, bool fill_dead, u32 *clear_flag = nullptr) {
   const PwSizes z = pw_sizes(p);
-  void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *flag = nullptr;
+  void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *flag = clear_flag;
   int rc = MMH_OK;
   auto grab = [&](void **b, size_t bytes) {
     if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
@@ -691,13 +728,15 @@ static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_
   grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
   grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
   grab(&w8, z.w8_bytes());
-  grab(&flag, 4);
+  if (!clear_flag) grab(&flag, 4);
   if (rc) set_error("pointwise_mac: allocation failed");
-  if (!rc) rc = pointwise_weights(p, d_filters_raw, d_filter_pts, (u32 *)wp, (u64 *)wl, (uint8_t *)w8, (u32 *)flag, s);
+  if (!rc)
+    rc = pointwise_weights(p, d_filters_raw, d_filter_pts, (u32 *)wp, (u64 *)wl, (uint8_t *)w8, (u32 *)flag, s,
+                           clear_flag != nullptr);
   if (!rc)
     rc = pointwise_product(p, image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8, (const u32 *)flag, acc, s,
                            fill_dead);
-  for (void *b : {wp, wl, w8, flag})
+  for (void *b : {wp, wl, w8, clear_flag ? nullptr : flag})
     if (b) (void)scratch_free(b, s);
   return rc;
 }
@@ -951,24 +990,25 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                             const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
                             const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream,
                             const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr,
-                            const mmh_conv_filters *prepared = nullptr) {
+                            const mmh_conv_filters *prepared = nullptr, const uint64_t *d_share_raw = nullptr) {
   const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
   MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!prepared || prepared->plan == p, MMH_ERR_INVALID_ARG);
   MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw || prepared) && d_pk_ntt_last && d_u && d_e1 && d_mask &&
                   d_out_cts && d_out_share,
               MMH_ERR_NULL_POINTER);
-  MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts || d_share_raw, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
   const mmh_ctx *ctx = p->ctx;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
   void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr, *mask_t = nullptr;
+  void *flag_word = nullptr;   // the direct route's weight-form flag, cleared by the kernel that builds the image
   // the route: prepared filters carry the one they were prepared for
   const bool direct = prepared ? prepared->w8 != nullptr : p->direct_fresh;
   int rc = MMH_OK;
   auto cleanup = [&]() {
-    for (void *b : {image, acc, zero, f_ntt, mask_t})
+    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word})
       if (b) (void)scratch_free(b, s);
   };
   auto grab = [&](void **b, size_t bytes) {
@@ -978,10 +1018,23 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   grab(&acc, p->n_out * 4 * N * 8);
   if (!direct && !prepared) grab(&f_ntt, M * Cs * 2 * N * 8);
   // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
-  if (!rc && p->meta.is_shared_input) rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
-  if (!rc && !p->meta.is_shared_input &&
-      hipMemcpyAsync(image, d_in_cts, p->n_in * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
-    rc = MMH_ERR_INTERNAL;
+  if (!rc && d_share_raw && p->meta.is_shared_input) {
+    if (direct && !prepared) grab(&flag_word, 4);
+    if (!rc) {
+      const size_t total = p->n_in << ctx->logN;
+      hipLaunchKernelGGL(image_plus_share_kernel, dim3(nblk(total)), dim3(256), 0, s, d_in_cts, d_share_raw,
+                         (u64 *)image, p->d_windows, p->n_in, ctx->logN, (int)p->split.win_c, (int)p->split.win_h,
+                         (int)p->split.win_w, (int)p->in.h, (int)p->in.w, p->sub_h, p->sub_w, ctx->bfv, ctx->d_mods,
+                         (u32 *)flag_word, flag_word ? 1 : 0);
+      if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+    }
+  } else {
+    if (!rc && p->meta.is_shared_input)
+      rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
+    if (!rc && !p->meta.is_shared_input &&
+        hipMemcpyAsync(image, d_in_cts, p->n_in * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      rc = MMH_ERR_INTERNAL;
+  }
   if (!rc && !direct) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
@@ -989,7 +1042,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
                            (u64 *)acc, s, exact, prepared->form);
   if (!rc && direct && !prepared)
-    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact);
+    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
   if (!rc && !direct && !prepared && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
@@ -1053,6 +1106,16 @@ extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d
   MMH_REQUIRE(d_filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask,
                           d_out_cts, d_out_share, stream);
+}
+
+extern "C" int mmh_conv_server_tensors(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share,
+                                       const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                                       const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                                       uint64_t *d_out_share, void *stream) {
+  MMH_REQUIRE(p && d_filters, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share, MMH_ERR_DIM_MISMATCH);
+  return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
+                          d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr);
 }
 
 extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {

@@ -123,6 +123,10 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
     # the one-call form from the raw filters (encode + lift + NTT on chip) gives the same bits
     one_out, one_share = server.conv2DSSFromWeights(got_cts, got_s, dev(filters), meta, (dev(u), dev(e1), dev(mask)))
     assert np.array_equal(host(one_out), ref_out)
+    # ... and so does the form that also takes the server's share as the raw tensor (CheetahLinear::conv2d in one call)
+    t_out, t_share = server.conv2DSSFromTensors(got_cts, dev(share1) if shared else None, dev(filters), meta,
+                                                (dev(u), dev(e1), dev(mask)))
+    assert np.array_equal(host(t_out), ref_out) and np.array_equal(host(t_share), ref_share)
     assert np.array_equal(host(one_share), ref_share)
     # ... and so does the call on filters prepared once (static weights)
     prep = server.prepareFilters(dev(filters), meta)

@@ -29,7 +29,7 @@ rand = (rnd(-1, 2, plan.n_out, N), rnd(-8, 9, plan.n_out, N), rnd(0, 1 << 62, pl
 if os.environ.get("TWO_CALL"):
     layer = lambda: srv.conv2DSS(cts, srv.encodeImage(share, meta), srv.encodeFilters(filters, meta), meta, rand)
 else:
-    layer = lambda: srv.conv2DSSFromWeights(cts, srv.encodeImage(share, meta), filters, meta, rand)
+    layer = lambda: srv.conv2DSSFromTensors(cts, share, filters, meta, rand)
 layer()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
