@@ -273,11 +273,13 @@ int mmh_conv_server_weights(const mmh_conv_plan *plan, const uint64_t *d_in_cts,
  * encodeFilters, conv2DSS) in one call: as mmh_conv_server_weights, but the server's share arrives as the raw
  * tensor d_share [C][H][W] (ignored when the plan's input is not shared) and is encoded inside the pass that adds
  * it to the ciphertexts; no share plaintexts are written.  Bit-identical to mmh_conv_encode_image followed by
- * mmh_conv_server_weights. */
+ * mmh_conv_server_weights.  d_zero_filter (device word, may be null): when given, the call also evaluates the
+ * conv2DOneFilter :573-580 rule as mmh_conv_check_filters does (1 when some filter is all zero mod t, else 0);
+ * the caller reads it back after enqueuing and treats 1 as the reference's error. */
 int mmh_conv_server_tensors(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share,
                             const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
-                            uint64_t *d_out_share, void *stream);
+                            uint64_t *d_out_share, uint32_t *d_zero_filter, void *stream);
 /* The conv2DOneFilter :573-580 rule on the raw filters [M][C][fh][fw]: *d_flag (device word) becomes 1
  * when some filter is all zero mod t, else 0.  Asynchronous, so a caller can read the verdict back after
  * it has enqueued the layer. */

@@ -101,9 +101,11 @@ __global__ __launch_bounds__(256) void image_plus_share_kernel(const u64 *__rest
                                                                int logN, int wc, int wh, int ww, int H, int W,
                                                                int sub_h, int sub_w, BfvConsts b,
                                                                const DevMod *__restrict__ mods,
-                                                               u32 *__restrict__ words, int n_words) {
+                                                               u32 *__restrict__ words, int n_words,
+                                                               u32 *__restrict__ one_more) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < (size_t)n_words) words[idx] = 0;
+  if (idx == 0 && one_more) *one_more = 0;
   if (idx >= (n_in << logN)) return;
   const size_t k = idx >> logN;
   const int i = (int)(idx & ((size_t(1) << logN) - 1));
@@ -215,53 +217,66 @@ int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t g
 constexpr int kPwMaxWc = 160;  // break-even against the transform route
 constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as w + 2^20
 
-// weights [M][C] (mod t) -> biased 32-bit form wp[Cpad][Mpad], lifted 64-bit form wl[2][Cpad][Mpad], signed byte
-// digits w8 in matrix-core fragment order (pw_mfma_kernel), and a flag word: bit 0 when some weight does not
-// fit the fast forms (|w| >= 2^20), bit 1 when some weight needs a third byte digit.  FROM_PTS: read them
-// back from encoded filter plaintexts instead of the raw tensor.
+// weights [M][K] (mod t; K = C*fh*fw taps) -> biased 32-bit form wp[Cpad][Mpad], lifted 64-bit form
+// wl[2][Cpad][Mpad], signed byte digits w8 in matrix-core fragment order (pw_mfma_kernel), and a flag word: bit 0
+// when some weight does not fit the fast forms (|w| >= 2^20), bit 1 when some weight needs a third byte digit.
+// One thread per filter and group of 16 taps: a 128-byte run of the raw tensor in, one 16-byte fragment per digit
+// out.  nzmap (optional, [M], cleared by the caller): word m becomes 1 when filter m has a weight that is not 0
+// mod t (the conv2DOneFilter :573-580 rule is evaluated from it by pw_expand_kernel).
+// FROM_PTS: read the weights back from encoded filter plaintexts instead of the raw tensor.
 // w8 layout: [m / 128][k / 64][digit 3][(m % 128) / 16][lane = ((k % 64) / 16) << 4 | m % 16][k % 16].
 template <bool FROM_PTS>
 __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__ src, u32 *__restrict__ wp,
-                                                         u64 *__restrict__ wl, uint8_t *__restrict__ w8,
-                                                         u32 *__restrict__ flag, int M, int Mpad, int Mpad128, int C,
-                                                         int Cpad, int Cpad64, const PwChannel *__restrict__ chan,
-                                                         int n_cslices, int logN, ModC t, u64 thr, u64 q0, u64 q1) {
+                                                         u64 *__restrict__ wl, uint4 *__restrict__ w8,
+                                                         u32 *__restrict__ flag, u32 *__restrict__ nzmap, int M,
+                                                         int Mpad, int Mpad128, int C, int Cpad, int Cpad64,
+                                                         const PwChannel *__restrict__ chan, int n_cslices, int logN,
+                                                         ModC t, u64 thr, u64 q0, u64 q1) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)Cpad64 * Mpad128) return;
-  const int m = (int)(gid % Mpad128), ch = (int)(gid / Mpad128);
-  u64 v = 0;  // filters and channels beyond the real ones weigh nothing
-  if (m < M && ch < C) {
-    if (FROM_PTS) {
-      const PwChannel pc = chan[ch];   // the tap's coefficient in the polynomial of its channel slice
-      v = src[(((size_t)m * n_cslices + pc.row) << logN) + pc.e];
-    } else {
-      v = red_t(src[(size_t)m * C + ch], t);
+  if (gid >= (size_t)(Cpad64 / 16) * Mpad128) return;
+  const int m = (int)(gid % Mpad128), kg = (int)(gid / Mpad128);
+  u32 dig[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  u32 bits = 0;
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int ch = kg * 16 + j;
+    u64 v = 0;  // filters and taps beyond the real ones weigh nothing
+    if (m < M && ch < C) {
+      if (FROM_PTS) {
+        const PwChannel pc = chan[ch];   // the tap's coefficient in the polynomial of its channel slice
+        v = src[(((size_t)m * n_cslices + pc.row) << logN) + pc.e];
+      } else {
+        v = red_t(src[(size_t)m * C + ch], t);
+      }
+    }
+    any |= v != 0;
+    const bool neg = v >= thr;
+    const u64 mag = neg ? t.q - v : v;
+    const bool fits = mag < (u64(1) << kPwBiasLog);
+    // balanced byte digits of the signed weight: w = d0 + 256 d1 + 65536 d2, d0 and d1 in [-128, 127]
+    const int w = fits ? (neg ? -(int)mag : (int)mag) : 0;
+    const int wb = w + 0x8080;
+    const int d2 = wb >> 16;
+    if (!fits) bits |= 1u;
+    if (d2 != 0) bits |= 2u;
+    const int sh = 8 * (j & 3);
+    dig[0][j >> 2] |= (u32)((wb & 0xff) ^ 0x80) << sh;
+    dig[1][j >> 2] |= (u32)(((wb >> 8) & 0xff) ^ 0x80) << sh;
+    dig[2][j >> 2] |= (u32)(d2 & 0xff) << sh;
+    if (m < Mpad && ch < Cpad) {
+      const size_t idx = (size_t)ch * Mpad + m;
+      wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
+      wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
+      wl[(size_t)Cpad * Mpad + idx] = neg ? v + (q1 - t.q) : v;      // limb 1
     }
   }
-  const bool neg = v >= thr;
-  const u64 mag = neg ? t.q - v : v;
-  const bool fits = mag < (u64(1) << kPwBiasLog);
-  // balanced byte digits of the signed weight: w = d0 + 256 d1 + 65536 d2, d0 and d1 in [-128, 127]
-  const int w = fits ? (neg ? -(int)mag : (int)mag) : 0;
-  const int wb = w + 0x8080;
-  const int d2 = wb >> 16;
-  u32 bits = fits ? 0u : 1u;
-  if (d2 != 0) bits |= 2u;
   if (bits) atomicOr(flag, bits);
-  {
-    const int kc = ch >> 6, k = ch & 63;
-    const size_t unit = ((((size_t)(m >> 7) * (Cpad64 >> 6) + kc) * 3) * 8 + ((m & 127) >> 4)) * 64 + (((k >> 4) << 4) | (m & 15));
-    uint8_t *dst = w8 + unit * 16 + (k & 15);
-    dst[0] = (uint8_t)((wb & 0xff) ^ 0x80);
-    dst[8 * 64 * 16] = (uint8_t)(((wb >> 8) & 0xff) ^ 0x80);
-    dst[2 * 8 * 64 * 16] = (uint8_t)d2;
-  }
-  if (m < Mpad && ch < Cpad) {
-    const size_t idx = (size_t)ch * Mpad + m;
-    wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
-    wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
-    wl[(size_t)Cpad * Mpad + idx] = neg ? v + (q1 - t.q) : v;      // limb 1
-  }
+  if (nzmap && any && m < M && nzmap[m] == 0) atomicOr(nzmap + m, 1u);
+  const int kc = kg >> 2;
+  const size_t unit = ((((size_t)(m >> 7) * (Cpad64 >> 6) + kc) * 3) * 8 + ((m & 127) >> 4)) * 64 + (((kg & 3) << 4) | (m & 15));
+#pragma unroll
+  for (int a = 0; a < 3; ++a) w8[unit + (size_t)a * 8 * 64] = make_uint4(dig[a][0], dig[a][1], dig[a][2], dig[a][3]);
 }
 
 // Two filters against both halves of one column value: four independent v_mad_u64_u32 in one asm
@@ -440,7 +455,15 @@ constexpr u64 kDigitBias = 0x0080808080808080ull;
 __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ image,
                                                         const PwChannel *__restrict__ chan,
                                                         const int *__restrict__ live, uint4 *__restrict__ u8,
-                                                        const u32 *__restrict__ flag, int KC, size_t S, int logN) {
+                                                        const u32 *__restrict__ flag, int KC, size_t S, int logN,
+                                                        const u32 *__restrict__ nzmap, int M,
+                                                        u32 *__restrict__ zero_filter) {
+  // conv2DOneFilter :573-580: some filter all zero mod t?  One workgroup reads the map pw_weights_kernel left.
+  if (nzmap && blockIdx.x == 0 && blockIdx.y == 0) {
+    int bad = 0;
+    for (int m = threadIdx.x; m < M; m += 256) bad |= nzmap[m] == 0;
+    if (bad) atomicOr(zero_filter, 1u);
+  }
   if (*flag & 1u) return;
   const size_t c0 = (size_t)live[blockIdx.x] * 64;   // first column of the tile: (sp, c0/c1, limb, i)
   const int kc = blockIdx.y, N = 1 << logN;
@@ -651,6 +674,10 @@ static bool pw_use_mfma() {  // MMH_CONV_PW_MFMA=0 keeps the fast form on the ve
   const char *e = getenv("MMH_CONV_PW_MFMA");
   return !(e && e[0] == '0');
 }
+// (the product's epilogue needs moduli of at least 40 bits for its k*q offset; SEAL's are 49 and 60)
+static bool pw_mfma_enabled(const mmh_ctx *ctx) {
+  return pw_use_mfma() && (ctx->q[0] >> 39) != 0 && (ctx->q[1] >> 39) != 0;
+}
 static PwSizes pw_sizes(const mmh_conv_plan *p) {
   PwSizes z;
   z.M = (int)p->meta.n_filters, z.Mpad = (z.M + 63) / 64 * 64, z.C = (int)p->f.count(), z.wc = (int)p->split.win_c;
@@ -660,24 +687,28 @@ static PwSizes pw_sizes(const mmh_conv_plan *p) {
 }
 // weights of the 1x1 route from the raw filters or from encoded plaintexts; flag must be zeroed first
 static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, const u64 *d_filter_pts, u32 *wp,
-                             u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s, bool flag_is_clear = false) {
+                             u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s, bool flag_is_clear = false,
+                             u32 *nzmap = nullptr) {
   const mmh_ctx *ctx = p->ctx;
   const PwSizes z = pw_sizes(p);
   if (!flag_is_clear) MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
   if (d_filters_raw)
-    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
-                       d_filters_raw, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, p->d_pw_chan,
+    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)(z.Cpad64 / 16) * z.Mpad128)), dim3(256), 0, s,
+                       d_filters_raw, wp, wl, (uint4 *)w8, flag, nzmap, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64,
+                       p->d_pw_chan,
                        (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
   else
-    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)z.Cpad64 * z.Mpad128)), dim3(256), 0, s,
-                       d_filter_pts, wp, wl, w8, flag, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, p->d_pw_chan,
+    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)(z.Cpad64 / 16) * z.Mpad128)), dim3(256), 0, s,
+                       d_filter_pts, wp, wl, (uint4 *)w8, flag, nzmap, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64,
+                       p->d_pw_chan,
                        (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
-                             const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1) {
+                             const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1,
+                             const u32 *nzmap = nullptr, u32 *zero_filter = nullptr) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const PwSizes z = pw_sizes(p);
@@ -689,8 +720,7 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
                        p->d_keep, p->d_pw_chan, acc, z.M, z.Mpad, z.Cpad, S, ctx->logN, ctx->d_mods);
   };
   // the device-side flag picks the kernel that runs; a caller that already knows the form skips the other
-  // (the epilogue's k*q offset needs moduli of at least 40 bits; SEAL's are 49 and 60)
-  const bool mfma = pw_use_mfma() && (ctx->q[0] >> 39) != 0 && (ctx->q[1] >> 39) != 0;
+  const bool mfma = pw_mfma_enabled(ctx);
   if (mfma && form != 1) {
     // fast form on the matrix cores: byte digits of the rotated columns once, then the i8 products
     const int KC = z.Cpad64 / 64, MT = z.Mpad128 / 128, n_live = (int)p->pw_live_tiles;
@@ -701,7 +731,7 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     }
     if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
     hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_chan,
-                       p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN);
+                       p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter);
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
                        ctx->logN, ctx->d_mods);
@@ -718,7 +748,8 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
   return MMH_OK;
 }
 static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_filters_raw,
-                         const u64 *d_filter_pts, u64 *acc, hipStream_t s, bool fill_dead, u32 *clear_flag = nullptr) {
+                         const u64 *d_filter_pts, u64 *acc, hipStream_t s, bool fill_dead, u32 *clear_flag = nullptr,
+                         u32 *nzmap = nullptr, u32 *zero_filter = nullptr) {
   const PwSizes z = pw_sizes(p);
   void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *flag = clear_flag;
   int rc = MMH_OK;
@@ -732,10 +763,10 @@ static int pointwise_mac(const mmh_conv_plan *p, const u64 *image, const u64 *d_
   if (rc) set_error("pointwise_mac: allocation failed");
   if (!rc)
     rc = pointwise_weights(p, d_filters_raw, d_filter_pts, (u32 *)wp, (u64 *)wl, (uint8_t *)w8, (u32 *)flag, s,
-                           clear_flag != nullptr);
+                           clear_flag != nullptr, nzmap);
   if (!rc)
     rc = pointwise_product(p, image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8, (const u32 *)flag, acc, s,
-                           fill_dead);
+                           fill_dead, -1, nzmap, zero_filter);
   for (void *b : {wp, wl, w8, clear_flag ? nullptr : flag})
     if (b) (void)scratch_free(b, s);
   return rc;
@@ -990,7 +1021,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                             const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
                             const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream,
                             const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr,
-                            const mmh_conv_filters *prepared = nullptr, const uint64_t *d_share_raw = nullptr) {
+                            const mmh_conv_filters *prepared = nullptr, const uint64_t *d_share_raw = nullptr,
+                            uint32_t *d_zero_filter = nullptr) {
   const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
   MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!prepared || prepared->plan == p, MMH_ERR_INVALID_ARG);
@@ -1018,22 +1050,37 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   grab(&acc, p->n_out * 4 * N * 8);
   if (!direct && !prepared) grab(&f_ntt, M * Cs * 2 * N * 8);
   // conv2DSS :655-671: image = share0 + Delta*share1 (or share0 alone), then to NTT form once
-  if (!rc && d_share_raw && p->meta.is_shared_input) {
-    if (direct && !prepared) grab(&flag_word, 4);
+  // The conv2DOneFilter :573-580 verdict, when the caller wants it from this call: on the direct route it falls
+  // out of the weight pass (a map of filters with a non-zero weight, read by the next kernel), else a pass of its own
+  const bool via_image_kernel = d_share_raw && p->meta.is_shared_input;
+  const bool nz_inline = d_zero_filter && via_image_kernel && direct && !prepared && d_filters_raw && pw_mfma_enabled(ctx);
+  if (!rc && via_image_kernel) {
+    const int n_words = direct && !prepared ? 1 + (nz_inline ? (int)M : 0) : 0;
+    if (n_words) grab(&flag_word, 4 * (size_t)n_words);
     if (!rc) {
       const size_t total = p->n_in << ctx->logN;
       hipLaunchKernelGGL(image_plus_share_kernel, dim3(nblk(total)), dim3(256), 0, s, d_in_cts, d_share_raw,
                          (u64 *)image, p->d_windows, p->n_in, ctx->logN, (int)p->split.win_c, (int)p->split.win_h,
                          (int)p->split.win_w, (int)p->in.h, (int)p->in.w, p->sub_h, p->sub_w, ctx->bfv, ctx->d_mods,
-                         (u32 *)flag_word, flag_word ? 1 : 0);
+                         (u32 *)flag_word, n_words, d_zero_filter);
       if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
     }
   } else {
+    if (!rc && d_zero_filter && hipMemsetAsync(d_zero_filter, 0, 4, s) != hipSuccess) rc = MMH_ERR_INTERNAL;
     if (!rc && p->meta.is_shared_input)
       rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, p->n_in, 0, (u64 *)image, stream);
     if (!rc && !p->meta.is_shared_input &&
         hipMemcpyAsync(image, d_in_cts, p->n_in * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
       rc = MMH_ERR_INTERNAL;
+  }
+  if (!rc && d_zero_filter && !nz_inline) {
+    if (!d_filters_raw) {
+      rc = MMH_ERR_INVALID_ARG;
+    } else {
+      hipLaunchKernelGGL(zero_filter_kernel, dim3((unsigned)M), dim3(256), 0, s, d_filters_raw, (size_t)p->f.count(),
+                         ctx->bfv.t, d_zero_filter);
+      if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+    }
   }
   if (!rc && !direct) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
@@ -1042,7 +1089,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
                            (u64 *)acc, s, exact, prepared->form);
   if (!rc && direct && !prepared)
-    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
+    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word,
+                       nz_inline ? (u32 *)flag_word + 1 : nullptr, nz_inline ? d_zero_filter : nullptr);
   if (!rc && !direct && !prepared && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,
@@ -1111,11 +1159,12 @@ extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d
 extern "C" int mmh_conv_server_tensors(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share,
                                        const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                                        const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
-                                       uint64_t *d_out_share, void *stream) {
+                                       uint64_t *d_out_share, uint32_t *d_zero_filter, void *stream) {
   MMH_REQUIRE(p && d_filters, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share, MMH_ERR_DIM_MISMATCH);
   return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
-                          d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr);
+                          d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr,
+                          d_zero_filter);
 }
 
 extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {

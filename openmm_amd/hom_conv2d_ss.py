@@ -216,7 +216,10 @@ class HomConv2DSS:
     # encodeImage + encodeFilters + conv2DSS as CheetahLinear::conv2d chains them (cheetah-api.cpp:401-445), in one
     # device call from the raw tensors: the server's share [C, H, W] (None when the input is not shared) and the
     # filters [M, C, fh, fw]; bit-identical to the three-call form
-    def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand):
+    def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand, inline_verdict=False):
+        """inline_verdict: let the layer call evaluate the zero-filter rule itself (one launch less); the verdict
+        is then known only when the whole call has run, so the default checks the filters ahead of the call and
+        waits for that early verdict alone, which lets the host enqueue the next call meanwhile"""
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
         self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
@@ -227,9 +230,10 @@ class HomConv2DSS:
                        "encodeImage: image shape")
             share_tensor = share_tensor.contiguous()
         filters = filters.contiguous()
-        bad = torch_empty_flag(filters)
-        L.check(self.ctx.lib.mmh_conv_check_filters(p.handle, L.dptr(filters), L.dptr(bad), L._stream_ptr()))
-        nz = L.DeferredFlag(bad, negate=True)   # true when no filter is all zero
+        bad = torch_empty_flag(filters)   # zero-filter verdict
+        if not inline_verdict:
+            L.check(self.ctx.lib.mmh_conv_check_filters(p.handle, L.dptr(filters), L.dptr(bad), L._stream_ptr()))
+            nz = L.DeferredFlag(bad, negate=True)   # true when no filter is all zero
         self._check_rand(p, rand, ("u", "e1", "mask"))
         u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
@@ -237,7 +241,10 @@ class HomConv2DSS:
         L.check(self.ctx.lib.mmh_conv_server_tensors(p.handle, L.dptr(img_share0),
                                                      L.dptr(share_tensor if meta.is_shared_input else None),
                                                      L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
-                                                     L.dptr(mask), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+                                                     L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
+                                                     L.dptr(bad if inline_verdict else None), L._stream_ptr()))
+        if inline_verdict:
+            nz = L.DeferredFlag(bad, negate=True)
         self._need(bool(nz), 8, "conv2DOneFilter: filter with all zero is not supported")
         return out_cts, out_share
 

@@ -81,7 +81,7 @@ SIGNATURES = {
     "mmh_flood_add": [_vp, _vp, _vp, _sz, _vp],
     "mmh_reduce_mod_t": [_vp, _vp, _vp, _sz, _vp],
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "mmh_conv_server_tensors": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server_tensors": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_check_filters": [_vp, _vp, _vp, _vp],
     "mmh_conv_filters_prepare": [_vp, _vp, C.POINTER(_vp), _vp],
     "mmh_conv_filters_destroy": [_vp],

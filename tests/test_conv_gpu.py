@@ -1,6 +1,8 @@
 """GPU parity of the HomConv2DSS layer calls (C ABI via the Python mirror) against the
 oracle's reference-shaped flow: encoders, encrypted image, server output ciphertexts, share
 tensor and decrypted tensor, bit for bit on identical randomness."""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,7 +127,7 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
     assert np.array_equal(host(one_out), ref_out)
     # ... and so does the form that also takes the server's share as the raw tensor (CheetahLinear::conv2d in one call)
     t_out, t_share = server.conv2DSSFromTensors(got_cts, dev(share1) if shared else None, dev(filters), meta,
-                                                (dev(u), dev(e1), dev(mask)))
+                                                (dev(u), dev(e1), dev(mask)), inline_verdict=route == "1")
     assert np.array_equal(host(t_out), ref_out) and np.array_equal(host(t_share), ref_share)
     assert np.array_equal(host(one_share), ref_share)
     # ... and so does the call on filters prepared once (static weights)
@@ -216,6 +218,24 @@ def test_conv_errors(mm):
     with pytest.raises(mm.MMHError) as ei:
         h.conv2DSS(cts, s1, h.encodeFilters(filters, meta), meta, (z, z, z))
     assert ei.value.code == 8
+    # the one-call form evaluates the rule itself: on the direct route from the weight pass, on the transform
+    # route and for unshared inputs by a pass of its own; good filters must not trip it
+    share = torch.zeros((3, 8, 8), dtype=torch.int64, device="cuda")
+    good = torch.ones((2, 3, 3, 3), dtype=torch.int64, device="cuda")
+    for route in ("0", "1"):
+        os.environ["MMH_CONV_POINTWISE"] = route
+        try:
+            for shared in (True, False):
+                h2 = HomConv2DSS()
+                h2.setUp(g, pk_ntt=torch.zeros((2, 2, N), dtype=torch.int64, device="cuda"))
+                m2 = Meta((3, 8, 8), (3, 3, 3), 2, 1, 1, shared)
+                for inline in (False, True):
+                    with pytest.raises(mm.MMHError) as ei:
+                        h2.conv2DSSFromTensors(cts, share if shared else None, filters, m2, (z, z, z), inline)
+                    assert ei.value.code == 8
+                    h2.conv2DSSFromTensors(cts, share if shared else None, good, m2, (z, z, z), inline)
+        finally:
+            del os.environ["MMH_CONV_POINTWISE"]
 
 
 def test_sharded_conv_single_rank_equals_unsharded(mm):
