@@ -31,6 +31,7 @@ CASES = [
     ((40, 14, 14), (1, 1), 3, 0, 1, True),     # 20 channels per polynomial, 40 channels = three staging chunks
     ((1, 4, 4), (1, 1), 1, 0, 1, True),        # smallest layer: one channel, one filter, one ciphertext
     ((1, 5, 5), (3, 3), 1, 1, 1, False),       # smallest 3x3 layer
+    ((520, 7, 7), (3, 3), 2, 1, 1, True),      # 4680 taps: near the direct route's limit (74 steps of 64 taps)
 ]
 
 
@@ -52,14 +53,19 @@ def host(t):
     return t.cpu().numpy().view(np.uint64)
 
 
-@pytest.mark.parametrize("wbound", [1 << 12, 1 << 36])
-def test_pointwise_route_general_weights(mm, wbound):
-    """1x1 route with weights up to the whole ring (|w| < 2^36 leaves its 21-bit fast form) against the
-    transform route on the same plan inputs; both must also equal the oracle's per-term schedule"""
+# weight magnitudes: two byte digits (< 32,640), three (< 2^20), beyond the fast forms (the whole ring);
+# layers: 1x1 with several filter tiles of 128, 3x3 with more than one 64-tap step
+@pytest.mark.parametrize("wbound", [1 << 12, 1 << 18, 1 << 36])
+@pytest.mark.parametrize("ishape,fhw,M,same", [((11, 28, 28), (1, 1), 5, 0), ((70, 14, 14), (1, 1), 140, 0),
+                                               ((9, 12, 12), (3, 3), 3, 1)])
+def test_direct_route_weight_forms(mm, monkeypatch, wbound, ishape, fhw, M, same):
+    """direct route forced, weights of every form, from the encoded plaintexts and from the raw tensors: all must
+    equal the oracle's per-term multiply_plain schedule bit for bit"""
     from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
-    ishape, fshape, M = (11, 28, 28), (11, 1, 1), 5
+    monkeypatch.setenv("MMH_CONV_POINTWISE", "1")
+    fshape = (ishape[0],) + tuple(fhw)
     o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
-    cv, meta = ConvOracle(o, ishape, fshape, M, 0, 1, True), Meta(ishape, fshape, M, 0, 1, True)
+    cv, meta = ConvOracle(o, ishape, fshape, M, same, 1, True), Meta(ishape, fshape, M, same, 1, True)
     sk, pk = keypair(o)
     server = HomConv2DSS()
     server.setUp(g, pk_ntt=dev(pk))
@@ -71,8 +77,11 @@ def test_pointwise_route_general_weights(mm, wbound):
     mask = rns_uniform(o, SEED + 8, cv.n_out, 1)[:, 0]
     ref_out, ref_share = cv.server(cts, s1, f, np.ascontiguousarray(pk[:, :1]), u, e1, mask)
     rand = (dev(u), dev(e1), dev(mask))
+    prep = server.prepareFilters(dev(filters), meta)
     for got in (server.conv2DSS(dev(cts), dev(s1), dev(f), meta, rand),
-                server.conv2DSSFromWeights(dev(cts), dev(s1), dev(filters), meta, rand)):
+                server.conv2DSSFromWeights(dev(cts), dev(s1), dev(filters), meta, rand),
+                server.conv2DSSFromTensors(dev(cts), dev(share1), dev(filters), meta, rand),
+                server.conv2DSSPrepared(dev(cts), dev(s1), prep, meta, rand)):
         assert np.array_equal(host(got[0]), ref_out) and np.array_equal(host(got[1]), ref_share)
 
 
