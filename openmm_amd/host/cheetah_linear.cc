@@ -289,18 +289,16 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
       for (size_t i = 0; i < f_words && !nz; ++i) nz = (fh[k * f_words + i] % base_mod_) != 0;
       if (!nz) throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
     }
-    Dev dfilt(fh.size()), spts;
+    Dev dfilt(fh.size());
     dfilt.upload(fh.data(), fh.size());
-    if (meta.is_shared_input) {
-      spts.alloc(n_in * N);
-      must(mmh_conv_encode_image(plan, img.p, spts.p, nullptr), "CheetahLinear::conv2d encodeImage");
-    }
     Dev cts = I.recv_cts(n_in, 2 * L * N);
     Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
     Dev out_cts(n_out * 2 * N), share(out_words);
-    // encodeFilters + conv2DSS (cheetah-api.cpp:417-445) in one device call
-    must(mmh_conv_server_weights(plan, cts.p, spts.p, dfilt.p, I.ring.pk_last.p, (const int64_t *)u.p,
-                                 (const int64_t *)e1.p, mask.p, out_cts.p, share.p, nullptr),
+    // encodeImage + encodeFilters + conv2DSS (cheetah-api.cpp:401-445) in one device call; the zero-filter rule
+    // was settled on the host copy above
+    must(mmh_conv_server_tensors(plan, cts.p, meta.is_shared_input ? img.p : nullptr, dfilt.p, I.ring.pk_last.p,
+                                 (const int64_t *)u.p, (const int64_t *)e1.p, mask.p, out_cts.p, share.p, nullptr,
+                                 nullptr),
          "CheetahLinear::conv2d conv2DSS:");
     share.download(out_tensor.data(), out_words);
     I.send_cts(out_cts, n_out, 2 * N);
