@@ -194,6 +194,54 @@ def test_conv_exact_reshare_with_flood_noise(mm):
     assert np.array_equal((dec.astype(object) + x_share.astype(object)) % t, ideal_conv(img, filters, 1, 1, t))
 
 
+def _random_layers(n, seed):
+    """small random layer geometries the reference accepts (fh <= fw, filter not larger than the image)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        fw = int(rng.choice([1, 1, 2, 3, 3, 5]))
+        fh = int(rng.integers(1, fw + 1))
+        h, w = int(rng.integers(fh, 40)), int(rng.integers(fw, 40))
+        c, m = int(rng.integers(1, 24)), int(rng.integers(1, 9))
+        stride, same = int(rng.choice([1, 1, 2])), int(rng.integers(0, 2))
+        if (h - fh) // stride < 0 or (w - fw) // stride < 0:
+            continue
+        out.append(((c, h, w), (fh, fw), m, same, stride, bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", _random_layers(24, 20260411))
+def test_random_layers_both_routes(mm, monkeypatch, ishape, fhw, M, same, stride, shared):
+    """random small geometries through the transform and the direct route against the oracle: output
+    ciphertexts and share tensor bit for bit, from the one-call form"""
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
+    fshape = (ishape[0],) + tuple(fhw)
+    try:
+        cv = ConvOracle(o, ishape, fshape, M, same, stride, shared)
+    except Exception:
+        pytest.skip("geometry the reference rejects")
+    meta = Meta(ishape, fshape, M, same, stride, shared)
+    sk, pk = keypair(o)
+    img, share0 = uniform_mod(SEED + 20, ishape, T), uniform_mod(SEED + 21, ishape, T)
+    share1 = (img - share0) & np.uint64(T - 1)
+    filters = signed_weights(SEED + 22, (M,) + fshape, 1 << 12, T)
+    a, e = rns_uniform(o, SEED + 30, cv.n_in, 2), noise(SEED + 31, (cv.n_in, N))
+    cts = cv.encrypt_image(sk, share0 if shared else img, a, e)
+    u, e1 = ternary(SEED + 40, (cv.n_out, N)), noise(SEED + 41, (cv.n_out, N))
+    mask = rns_uniform(o, SEED + 50, cv.n_out, 1)[:, 0]
+    ref_out, ref_share = cv.server(cts, cv.encode_image(share1) if shared else None, cv.encode_filters(filters),
+                                   np.ascontiguousarray(pk[:, :1]), u, e1, mask)
+    for route in ("0", "1"):
+        monkeypatch.setenv("MMH_CONV_POINTWISE", route)
+        server = HomConv2DSS()
+        server.setUp(g, pk_ntt=dev(pk))
+        got = server.conv2DSSFromTensors(dev(cts), dev(share1) if shared else None, dev(filters), meta,
+                                         (dev(u), dev(e1), dev(mask)))
+        assert np.array_equal(host(got[0]), ref_out), route
+        assert np.array_equal(host(got[1]), ref_share), route
+
+
 def test_conv_errors(mm):
     from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
     import torch
