@@ -105,7 +105,25 @@ def conversion_leg(torch, openmm_amd):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    return {"ring_to_field_1e7_pre_post_us": us, "ring_to_field_hbm_frac": 50.0 * n / (us * 1e-6) / HBM_PEAK}
+    res = {"ring_to_field_1e7_pre_post_us": us, "ring_to_field_hbm_frac": 50.0 * n / (us * 1e-6) / HBM_PEAK}
+    # Truncation::truncate (truncation-cheetah.cpp:2-82, no heuristic, signed, l=32, shift 12) on the same 10^7
+    # elements: pre (in -> adj, cmp: 24 B) and post (adj, aw -> out: 24 B) around the host compare + B2A
+    adj, cmp, aw = torch.empty_like(x), torch.empty_like(x), y & 0xFFF
+
+    def trunc():
+        L.check(lib.mmh_trunc_pre(1, L.dptr(x), n, l, 1, 0, L.dptr(adj), L.dptr(cmp), s))
+        L.check(lib.mmh_trunc_post(1, L.dptr(adj), L.dptr(aw), n, 12, l, 1, 0, L.dptr(out), s))
+
+    trunc()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        trunc()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    res.update({"truncate_1e7_pre_post_us": us, "truncate_hbm_frac": 48.0 * n / (us * 1e-6) / HBM_PEAK})
+    return res
 
 
 def layer_legs(torch, openmm_amd, local):

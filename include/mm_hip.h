@@ -428,6 +428,20 @@ int mmh_r2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const u
                  int bw_a, int bw_b, uint64_t *d_out, void *stream);
 int mmh_r2r128_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
                     int bw_a, int bw_b, uint64_t *d_out, void *stream);
+/* Local share arithmetic of Truncation::truncate / truncate_msb / truncate_msb0 in the shipped USE_CHEETAH build
+ * (SCI/src/BuildingBlocks/truncation-cheetah.cpp:2-218) around their wrap and B2A sub-protocols (OT-based, host).
+ * pre: d_adj = the input after the msb0 heuristic's +2^(bw-3) on BOB (:23-29) and the signed case's +2^(bw-1)
+ * on ALICE (:42-47, :102-107, :183-188); d_cmp (may be null) = the operand of mill->compare (:51-56).
+ * post: d_out from d_adj and the B2A output d_aw (:64-75, :133-144, :201-212, heuristic :32-34). */
+int mmh_trunc_pre(int party, const uint64_t *d_in, size_t n, int bw, int signed_arith, int heuristic,
+                  uint64_t *d_adj, uint64_t *d_cmp, void *stream);
+int mmh_trunc_post(int party, const uint64_t *d_adj, const uint64_t *d_aw, size_t n, int shift, int bw,
+                   int signed_arith, int heuristic, uint64_t *d_out, void *stream);
+/* Truncation::truncate_and_reduce (truncation.cpp:289-317): the operand of wrap_computation (:300-304) and the
+ * result in the ring of bw - shift bits from the B2A output d_aw (:311-313) */
+int mmh_trunc_reduce_pre(const uint64_t *d_in, size_t n, int shift, uint64_t *d_lower, void *stream);
+int mmh_trunc_reduce_post(const uint64_t *d_in, const uint64_t *d_aw, size_t n, int shift, int bw,
+                          uint64_t *d_out, void *stream);
 /* out[i] = (out[i] + moduloMult(x[i], y[i], p)) % p : the local cross term that closes
  * CheetahLinear::BOLE (cheetah-api.cpp:648-649; sci::moduloMult utils.hpp:353-363) */
 int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n, uint64_t p,

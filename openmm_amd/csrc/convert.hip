@@ -104,6 +104,45 @@ __global__ __launch_bounds__(256) void r2r_post_kernel(int party, const u64 *__r
 }
 
 // out = (out + (x mod p) * y mod p) mod p with the reference's wrapping u64 addition
+// Truncation::truncate / truncate_msb / truncate_msb0 of the USE_CHEETAH build (truncation-cheetah.cpp:2-218):
+// the share arithmetic before the wrap sub-protocol (heuristic offset on BOB :23-29, signed offset on ALICE
+// :42-47, operand of mill->compare :51-56) ...
+__global__ __launch_bounds__(256) void trunc_pre_kernel(int party, const u64 *__restrict__ in, size_t n, int bw,
+                                                        int signed_arith, int heuristic, u64 *__restrict__ adj,
+                                                        u64 *__restrict__ cmp) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 mask = bw_mask(bw);
+  u64 v = in[i];
+  if (heuristic && party != kAlice) v = (v + (u64(1) << (bw - 3))) & mask;
+  if (signed_arith && party == kAlice) v = (v + (u64(1) << (bw - 1))) & mask;
+  adj[i] = v;
+  if (cmp) {
+    const u64 c = v & mask;
+    cmp[i] = party == kAlice ? c : (mask - c) & mask;
+  }
+}
+// ... and after B2A (:64-75 = :133-144 = :201-212; heuristic :32-34); aw = arithmetic share of the wrap bit
+__global__ __launch_bounds__(256) void trunc_post_kernel(int party, const u64 *__restrict__ adj,
+                                                         const u64 *__restrict__ aw, size_t n, int shift, int bw,
+                                                         int signed_arith, int heuristic, u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 mask = bw_mask(bw);
+  u64 o = (((adj[i] >> shift) & bw_mask(bw - shift)) - (u64(1) << (bw - shift)) * aw[i]) & mask;
+  if (signed_arith && party == kAlice) o = (o - (u64(1) << (bw - shift - 1))) & mask;
+  if (heuristic && party != kAlice) o = (o - (u64(1) << (bw - 3 - shift))) & mask;
+  out[i] = o;
+}
+// Truncation::truncate_and_reduce (truncation.cpp:289-317): aw == nullptr gives the operand of
+// wrap_computation (:300-304), else the result in the smaller ring (:311-313)
+__global__ __launch_bounds__(256) void trunc_reduce_kernel(const u64 *__restrict__ in, const u64 *__restrict__ aw,
+                                                           size_t n, int shift, int bw, u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = aw ? ((in[i] >> shift) + aw[i]) & bw_mask(bw - shift) : in[i] & bw_mask(shift);
+}
+
 __global__ __launch_bounds__(256) void cross_term_kernel(u64 *__restrict__ out, const u64 *__restrict__ x,
                                                          const u64 *__restrict__ y, size_t n, u64 p, u64 r_hi,
                                                          u64 r_lo) {
@@ -203,6 +242,38 @@ extern "C" int mmh_r2r128_post(int party, const uint64_t *d_tmp, const uint8_t *
   LAUNCH1D(r2r_post_kernel<true>, n, stream, party, d_tmp, d_msb, d_y, n, bw_a, bw_b, d_out);
   return MMH_OK;
 }
+extern "C" int mmh_trunc_pre(int party, const uint64_t *d_in, size_t n, int bw, int signed_arith, int heuristic,
+                             uint64_t *d_adj, uint64_t *d_cmp, void *stream) {
+  MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(n == 0 || (d_in && d_adj), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= (heuristic ? 4 : 2) && bw <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(trunc_pre_kernel, n, stream, party, d_in, n, bw, signed_arith, heuristic, d_adj, d_cmp);
+  return MMH_OK;
+}
+extern "C" int mmh_trunc_post(int party, const uint64_t *d_adj, const uint64_t *d_aw, size_t n, int shift, int bw,
+                              int signed_arith, int heuristic, uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(n == 0 || (d_adj && d_aw && d_out), MMH_ERR_NULL_POINTER);
+  // the reference's asserts (truncation-cheetah.cpp:12-13); the heuristic's offset 2^(bw-3-shift) must exist
+  MMH_REQUIRE(bw >= 2 && bw <= 64 && shift >= 1 && bw - shift > 0 && (!heuristic || shift <= bw - 3),
+              MMH_ERR_INVALID_ARG);
+  LAUNCH1D(trunc_post_kernel, n, stream, party, d_adj, d_aw, n, shift, bw, signed_arith, heuristic, d_out);
+  return MMH_OK;
+}
+extern "C" int mmh_trunc_reduce_pre(const uint64_t *d_in, size_t n, int shift, uint64_t *d_lower, void *stream) {
+  MMH_REQUIRE(n == 0 || (d_in && d_lower), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(shift >= 1 && shift <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(trunc_reduce_kernel, n, stream, d_in, (const u64 *)nullptr, n, shift, 64, d_lower);
+  return MMH_OK;
+}
+extern "C" int mmh_trunc_reduce_post(const uint64_t *d_in, const uint64_t *d_aw, size_t n, int shift, int bw,
+                                     uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(n == 0 || (d_in && d_aw && d_out), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 2 && bw <= 64 && shift >= 1 && bw - shift > 0, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(trunc_reduce_kernel, n, stream, d_in, d_aw, n, shift, bw, d_out);
+  return MMH_OK;
+}
+
 extern "C" int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n,
                                    uint64_t p, void *stream) {
   MMH_REQUIRE(n == 0 || (d_out && d_x && d_y), MMH_ERR_NULL_POINTER);

@@ -107,4 +107,74 @@ void Truncation::ring_to_ring128(int32_t dim, uint64_t *inA, unsigned __int128 *
   must(mmh_r2r128_post(party, b.tmp, b.msb, b.y, dim, bw_A, bw_B, b.out, nullptr), "ring_to_ring128");
   d2h(outB, b.out, dim * 16ull);  // (lo, hi) pairs are the little-endian image of __uint128_t
 }
+// ---- the truncate family (truncation-cheetah.cpp): pre kernel, wrap sub-protocol, B2A, post kernel ----
+void Truncation::truncate_common(int32_t dim, uint64_t *inA, uint64_t *outB, int32_t shift, int32_t bw,
+                                 bool signed_arithmetic, bool heuristic, Wrap how, const uint8_t *msb_x) {
+  if (shift == 0) {  // :8-11
+    std::copy(inA, inA + dim, outB);
+    return;
+  }
+  if (!aux_) throw std::runtime_error("Truncation::truncate: no AuxProtocols");
+  if (!(bw - shift > 0) || inA == outB) throw std::invalid_argument("Truncation::truncate: bad shift / aliasing");  // :12-14
+  Bufs b(dim);
+  h2d(b.in, inA, dim * 8ull);
+  must(mmh_trunc_pre(party, b.in, dim, bw, signed_arithmetic, heuristic, b.tmp, b.corr, nullptr), "truncate");
+  std::vector<uint64_t> adj(dim), cmp(dim), aw(dim);
+  std::vector<uint8_t> wrap(dim);
+  d2h(adj.data(), b.tmp, dim * 8ull);
+  if (how == Wrap::kCompare) {  // :58
+    d2h(cmp.data(), b.corr, dim * 8ull);
+    aux_->compare(wrap.data(), cmp.data(), dim, bw);
+  } else if (how == Wrap::kMsb) {  // :118-127
+    std::vector<uint8_t> m(msb_x, msb_x + dim);
+    if (signed_arithmetic)
+      for (auto &v : m) v ^= party == ALICE ? 1 : 0;
+    aux_->MSB_to_Wrap(adj.data(), m.data(), wrap.data(), dim, bw);
+  } else if (signed_arithmetic) {  // :192-195
+    aux_->msb1_to_wrap(adj.data(), wrap.data(), dim, bw);
+  } else {
+    aux_->msb0_to_wrap(adj.data(), wrap.data(), dim, bw);
+  }
+  aux_->B2A(wrap.data(), aw.data(), dim, shift);  // :61
+  h2d(b.y, aw.data(), dim * 8ull);
+  must(mmh_trunc_post(party, b.tmp, b.y, dim, shift, bw, signed_arithmetic, heuristic, b.out, nullptr), "truncate");
+  d2h(outB, b.out, dim * 8ull);
+}
+
+void Truncation::truncate(int32_t dim, uint64_t *inA, uint64_t *outB, int32_t shift, int32_t bw,
+                          bool signed_arithmetic, uint8_t *msb_x, bool apply_msb0_heuristic) {
+  if (msb_x) return truncate_msb(dim, inA, outB, shift, bw, signed_arithmetic, msb_x);  // :5-6
+  if (apply_msb0_heuristic)  // :20-39: truncate_msb0 around BOB's +2^(bw-3) / -2^(bw-3-shift)
+    return truncate_common(dim, inA, outB, shift, bw, signed_arithmetic, true, Wrap::kMsb0, nullptr);
+  truncate_common(dim, inA, outB, shift, bw, signed_arithmetic, false, Wrap::kCompare, nullptr);
+}
+void Truncation::truncate_msb(int32_t dim, uint64_t *inA, uint64_t *outB, int32_t shift, int32_t bw,
+                              bool signed_arithmetic, uint8_t *msb_x) {
+  truncate_common(dim, inA, outB, shift, bw, signed_arithmetic, false, Wrap::kMsb, msb_x);
+}
+void Truncation::truncate_msb0(int32_t dim, uint64_t *inA, uint64_t *outB, int32_t shift, int32_t bw,
+                               bool signed_arithmetic) {
+  truncate_common(dim, inA, outB, shift, bw, signed_arithmetic, false, Wrap::kMsb0, nullptr);
+}
+
+// truncation.cpp:289-317
+void Truncation::truncate_and_reduce(int32_t dim, uint64_t *inA, uint64_t *outB, int32_t shift, int32_t bw) {
+  if (shift == 0) {
+    std::copy(inA, inA + dim, outB);
+    return;
+  }
+  if (!aux_) throw std::runtime_error("Truncation::truncate_and_reduce: no AuxProtocols");
+  if (!(bw - shift > 0)) throw std::invalid_argument("Truncation::truncate_and_reduce: bad shift");
+  Bufs b(dim);
+  h2d(b.in, inA, dim * 8ull);
+  must(mmh_trunc_reduce_pre(b.in, dim, shift, b.tmp, nullptr), "truncate_and_reduce");
+  std::vector<uint64_t> lower(dim), aw(dim);
+  std::vector<uint8_t> wrap(dim);
+  d2h(lower.data(), b.tmp, dim * 8ull);
+  aux_->wrap_computation(lower.data(), wrap.data(), dim, shift);
+  aux_->B2A(wrap.data(), aw.data(), dim, bw - shift);
+  h2d(b.y, aw.data(), dim * 8ull);
+  must(mmh_trunc_reduce_post(b.in, b.y, dim, shift, bw, b.out, nullptr), "truncate_and_reduce");
+  d2h(outB, b.out, dim * 8ull);
+}
 }  // namespace mm

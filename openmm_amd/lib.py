@@ -108,6 +108,10 @@ SIGNATURES = {
     "mmh_r2r_pre": [_int, _vp, _sz, _int, _vp, _vp, _vp, _vp],
     "mmh_r2r_post": [_int, _vp, _vp, _vp, _sz, _int, _int, _vp, _vp],
     "mmh_r2r128_post": [_int, _vp, _vp, _vp, _sz, _int, _int, _vp, _vp],
+    "mmh_trunc_pre": [_int, _vp, _sz, _int, _int, _int, _vp, _vp, _vp],
+    "mmh_trunc_post": [_int, _vp, _vp, _sz, _int, _int, _int, _int, _vp, _vp],
+    "mmh_trunc_reduce_pre": [_vp, _sz, _int, _vp, _vp],
+    "mmh_trunc_reduce_post": [_vp, _vp, _sz, _int, _int, _vp, _vp],
     "mmh_bole_cross_term": [_vp, _vp, _vp, _sz, _u64, _vp],
 }
 

@@ -60,12 +60,55 @@ class IdealCOT:
         return self._recv(choice, n, 0, p)
 
 
-class Truncation:
-    """Truncation(party, cot): the five conversion methods of the reference class."""
+class IdealAux:
+    """Loop-back ideal versions of the OT-based sub-protocols Truncation::truncate* call on ``aux`` / ``mill``
+    (SCI/src/BuildingBlocks/aux-protocols.h, Millionaire): each returns this party's share of the bit or value
+    the real protocol computes.  Two parties in two threads share one object; they must make the same calls in
+    the same order (as the real protocol requires).  Test double only, like ``IdealCOT``."""
 
-    def __init__(self, party, cot, device=0):
+    def __init__(self, seed=0x4D264D):
+        self._to = {ALICE: queue.Queue(), BOB: queue.Queue()}
+        self._rng = {ALICE: np.random.default_rng(seed), BOB: np.random.default_rng(seed)}   # run in lock step
+
+    def _swap(self, party, mine):
+        other = BOB if party == ALICE else ALICE
+        self._to[other].put(np.array(mine, copy=True))
+        return self._to[party].get()
+
+    def _bit_shares(self, party, bit):
+        r = self._rng[party].integers(0, 2, size=len(bit), dtype=np.uint8)
+        return r if party == ALICE else (bit.astype(np.uint8) ^ r)
+
+    @staticmethod
+    def _wraps(a, b, bw):   # 1{a + b >= 2^bw} for values below 2^bw
+        mask = (1 << bw) - 1
+        return np.array([(int(x) & mask) + (int(y) & mask) > mask for x, y in zip(a, b)], dtype=np.uint8)
+
+    def compare(self, party, data, dim, bw):          # mill->compare: shares of 1{ALICE's > BOB's}
+        other = self._swap(party, data)
+        a, b = (data, other) if party == ALICE else (other, data)
+        return self._bit_shares(party, (a > b).astype(np.uint8))
+
+    def wrap(self, party, x, dim, bw):                # MSB_to_Wrap / msb0_to_wrap / msb1_to_wrap / wrap_computation
+        other = self._swap(party, x)
+        return self._bit_shares(party, self._wraps(x, other, bw))
+
+    def B2A(self, party, bits, dim, bw):              # boolean shares -> arithmetic shares mod 2^bw
+        other = self._swap(party, bits)
+        bit = (np.asarray(bits, dtype=np.uint8) ^ np.asarray(other, dtype=np.uint8)).astype(np.uint64)
+        r = self._rng[party].integers(0, 1 << 62, size=dim, dtype=np.uint64) * np.uint64(4) + \
+            self._rng[party].integers(0, 4, size=dim, dtype=np.uint64)
+        mask = np.uint64((1 << bw) - 1) if bw < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+        return (r & mask) if party == ALICE else ((bit - r) & mask)
+
+
+class Truncation:
+    """Truncation(party, cot[, aux]): the five conversion methods of the reference class and, given ``aux``
+    (the wrap / compare / B2A sub-protocols), its truncate family."""
+
+    def __init__(self, party, cot, device=0, aux=None):
         assert party in (ALICE, BOB)
-        self.party, self.cot, self.device = party, cot, device
+        self.party, self.cot, self.device, self.aux = party, cot, device, aux
         self.lib = L.load_library()
 
     # -- helpers ---------------------------------------------------------------------
@@ -154,6 +197,58 @@ class Truncation:
         out = self._out(dim, 2)
         L.check(self.lib.mmh_r2r128_post(self.party, L.dptr(tmp), L.dptr(msb), L.dptr(y), dim, bw_A, bw_B,
                                          L.dptr(out), s))
+        return out
+
+
+    # -- truncation-cheetah.cpp (the shipped USE_CHEETAH build) ---------------------------------------
+    def _truncate(self, dim, inA, shift, bw, signed_arithmetic, heuristic, wrap_of):
+        """pre kernel, the wrap sub-protocol chosen by the caller, B2A, post kernel"""
+        if shift == 0:
+            return inA.clone()
+        assert bw - shift > 0 and (not signed_arithmetic or bw - shift - 1 >= 0)   # :12-13
+        s = L._stream_ptr()
+        adj, cmp = self._out(dim), self._out(dim)
+        L.check(self.lib.mmh_trunc_pre(self.party, L.dptr(inA), dim, bw, int(signed_arithmetic), int(heuristic),
+                                       L.dptr(adj), L.dptr(cmp), s))
+        wrap = wrap_of(L.to_host(adj), L.to_host(cmp))
+        aw = L.to_device(self.aux.B2A(self.party, wrap, dim, shift), f"cuda:{self.device}")
+        out = self._out(dim)
+        L.check(self.lib.mmh_trunc_post(self.party, L.dptr(adj), L.dptr(aw), dim, shift, bw,
+                                        int(signed_arithmetic), int(heuristic), L.dptr(out), s))
+        return out
+
+    # :2-82
+    def truncate(self, dim, inA, shift, bw, signed_arithmetic=True, msb_x=None, apply_msb0_heuristic=True):
+        if msb_x is not None:
+            return self.truncate_msb(dim, inA, shift, bw, signed_arithmetic, msb_x)
+        if apply_msb0_heuristic:   # :20-39: BOB adds 2^(bw-3) first and takes 2^(bw-3-shift) off afterwards
+            return self._truncate(dim, inA, shift, bw, signed_arithmetic, True,
+                                  lambda adj, cmp: self.aux.wrap(self.party, adj, dim, bw))
+        return self._truncate(dim, inA, shift, bw, signed_arithmetic, False,
+                              lambda adj, cmp: self.aux.compare(self.party, cmp, dim, bw))
+
+    # :84-151 (the sub-protocol gets msb_x, inverted on ALICE when signed, :118-127; the ideal one ignores it)
+    def truncate_msb(self, dim, inA, shift, bw, signed_arithmetic, msb_x):
+        return self._truncate(dim, inA, shift, bw, signed_arithmetic, False,
+                              lambda adj, cmp: self.aux.wrap(self.party, adj, dim, bw))
+
+    # :155-218
+    def truncate_msb0(self, dim, inA, shift, bw, signed_arithmetic=True):
+        return self._truncate(dim, inA, shift, bw, signed_arithmetic, False,
+                              lambda adj, cmp: self.aux.wrap(self.party, adj, dim, bw))
+
+    # -- truncation.cpp:289-317 --------------------------------------------------------------------------
+    def truncate_and_reduce(self, dim, inA, shift, bw):
+        if shift == 0:
+            return inA.clone()
+        assert bw - shift > 0
+        s = L._stream_ptr()
+        lower = self._out(dim)
+        L.check(self.lib.mmh_trunc_reduce_pre(L.dptr(inA), dim, shift, L.dptr(lower), s))
+        wrap = self.aux.wrap(self.party, L.to_host(lower), dim, shift)
+        aw = L.to_device(self.aux.B2A(self.party, wrap, dim, bw - shift), f"cuda:{self.device}")
+        out = self._out(dim)
+        L.check(self.lib.mmh_trunc_reduce_post(L.dptr(inA), L.dptr(aw), dim, shift, bw, L.dptr(out), s))
         return out
 
 

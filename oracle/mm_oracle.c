@@ -665,6 +665,46 @@ void mmo_r2r128_post(int party, const uint64_t *tmp, const uint8_t *msb, const u
   }
 }
 
+/* ---- Truncation::truncate / truncate_msb / truncate_msb0 of the USE_CHEETAH build (truncation-cheetah.cpp) and
+ * truncate_and_reduce (truncation.cpp:289-317): the local share arithmetic around their wrap / B2A sub-protocols.
+ * pre: the msb0 heuristic's +2^(bw-3) on BOB (truncation-cheetah.cpp:23-29), the signed case's +2^(bw-1) on ALICE
+ * (:42-47, :102-107, :183-188), and the operand of mill->compare (:51-56): adj & mask, on BOB mask - that. */
+void mmo_trunc_pre(int party, const uint64_t *in, size_t n, int bw, int signed_arith, int heuristic,
+                   uint64_t *adj, uint64_t *cmp) {
+  uint64_t mask = bw_mask(bw);
+  for (size_t i = 0; i < n; i++) {
+    uint64_t v = in[i];
+    if (heuristic && party != ALICE) v = (v + (((uint64_t)1) << (bw - 3))) & mask;
+    if (signed_arith && party == ALICE) v = (v + (((uint64_t)1) << (bw - 1))) & mask;
+    adj[i] = v;
+    if (cmp) {
+      uint64_t c = v & mask;
+      cmp[i] = party == ALICE ? c : (mask - c) & mask;
+    }
+  }
+}
+/* post: truncation-cheetah.cpp:64-75 (= :133-144 = :201-212) with aw the B2A output mod 2^shift, then the
+ * heuristic's -2^(bw-3-shift) on BOB (:32-34) */
+void mmo_trunc_post(int party, const uint64_t *adj, const uint64_t *aw, size_t n, int shift, int bw,
+                    int signed_arith, int heuristic, uint64_t *out) {
+  uint64_t mask = bw_mask(bw), mask_upper = bw_mask(bw - shift);
+  for (size_t i = 0; i < n; i++) {
+    uint64_t o = (((adj[i] >> shift) & mask_upper) - (((uint64_t)1) << (bw - shift)) * aw[i]) & mask;
+    if (signed_arith && party == ALICE) o = (o - (((uint64_t)1) << (bw - shift - 1))) & mask;
+    if (heuristic && party != ALICE) o = (o - (((uint64_t)1) << (bw - 3 - shift))) & mask;
+    out[i] = o;
+  }
+}
+/* truncation.cpp:300-304: the operand of wrap_computation; :311-313: the result in the smaller ring */
+void mmo_trunc_reduce_pre(const uint64_t *in, size_t n, int shift, uint64_t *lower) {
+  uint64_t mask_shift = bw_mask(shift);
+  for (size_t i = 0; i < n; i++) lower[i] = in[i] & mask_shift;
+}
+void mmo_trunc_reduce_post(const uint64_t *in, const uint64_t *aw, size_t n, int shift, int bw, uint64_t *out) {
+  uint64_t mask_out = bw_mask(bw - shift);
+  for (size_t i = 0; i < n; i++) out[i] = ((in[i] >> shift) + aw[i]) & mask_out;
+}
+
 void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, size_t n,
                    int l, uint64_t p, int prime, uint64_t *recv) {
   for (size_t i = 0; i < n; i++) {

@@ -163,6 +163,14 @@ void mmo_r2r_post(int party, const uint64_t *tmp, const uint8_t *msb, const uint
 /* 128-bit output as (lo,hi) pairs: out[2*i], out[2*i+1] */
 void mmo_r2r128_post(int party, const uint64_t *tmp, const uint8_t *msb, const uint64_t *y, size_t n,
                      int bw_a, int bw_b, uint64_t *out);
+/* local arithmetic of Truncation::truncate / truncate_msb / truncate_msb0 (truncation-cheetah.cpp:2-218) and
+ * truncate_and_reduce (truncation.cpp:289-317); aw = the B2A output of the wrap bit */
+void mmo_trunc_pre(int party, const uint64_t *in, size_t n, int bw, int signed_arith, int heuristic,
+                   uint64_t *adj, uint64_t *cmp);
+void mmo_trunc_post(int party, const uint64_t *adj, const uint64_t *aw, size_t n, int shift, int bw,
+                    int signed_arith, int heuristic, uint64_t *out);
+void mmo_trunc_reduce_pre(const uint64_t *in, size_t n, int shift, uint64_t *lower);
+void mmo_trunc_reduce_post(const uint64_t *in, const uint64_t *aw, size_t n, int shift, int bw, uint64_t *out);
 /* ideal COT functionality (silent_ot.h:111-116,198-204; pattern SCI/src/OT/ideal.h:106-156):
  * x = sender randomness (given), receiver gets x + b*corr mod 2^l (l<=64) or mod p (prime=1) */
 void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, size_t n,

@@ -131,6 +131,51 @@ int main(int argc, char **argv) {
     EXPECT(ok, "BatchNorm: ring_to_field -> bn -> field_to_ring exact");
   }
 
+  // ---- the truncate family (truncation-cheetah.cpp) with ideal wrap / B2A sub-protocols: floor(x / 2^k) up to
+  // the one unit Cheetah's truncation gives up; truncate_and_reduce exact --------------------------------------
+  {
+    auto abox = std::make_shared<mm::IdealAux::Mailbox>();
+    mm::IdealAux auxA(1, abox, 77), auxB(2, abox, 77);
+    mm::Truncation tA(1, A.cot.get(), &auxA), tB(2, B.cot.get(), &auxB);
+    std::vector<int64_t> v(n);
+    std::vector<u64> s[2], o[4][2], red[2];
+    s[0].resize(n), s[1].resize(n);
+    for (int i = 0; i < n; ++i) {
+      v[i] = (int64_t)(rng() % (1ULL << (bw - 3))) - (int64_t)(1ULL << (bw - 4));   // the heuristic's range
+      s[0][i] = rng() & mask;
+      s[1][i] = ((u64)v[i] - s[0][i]) & mask;
+    }
+    for (int q = 0; q < 2; ++q) {
+      for (auto &x : o) x[q].resize(n);
+      red[q].resize(n);
+    }
+    std::vector<uint8_t> no_msb(n, 0);
+    both(A, B, [&](Party &p) {
+      const int q = p.id - 1;
+      mm::Truncation &t = q ? tB : tA;
+      t.truncate(n, s[q].data(), o[0][q].data(), k, bw, true, nullptr, true);
+      t.truncate(n, s[q].data(), o[1][q].data(), k, bw, true, nullptr, false);
+      t.truncate_msb(n, s[q].data(), o[2][q].data(), k, bw, true, no_msb.data());
+      t.truncate_msb0(n, s[q].data(), o[3][q].data(), k, bw, true);
+      t.truncate_and_reduce(n, s[q].data(), red[q].data(), k, bw);
+    });
+    bool ok[4] = {true, true, true, true}, okr = true;
+    for (int i = 0; i < n; ++i) {
+      const int64_t want = v[i] >> k;
+      for (int z = 0; z < 4; ++z) {
+        const int64_t got = to_signed(o[z][0][i] + o[z][1][i], bw);
+        ok[z] = ok[z] && (got == want || got == want - 1);
+      }
+      const u64 mo = (1ULL << (bw - k)) - 1;
+      okr = okr && (((red[0][i] + red[1][i]) & mo) == ((((u64)v[i] & mask) >> k) & mo));
+    }
+    EXPECT(ok[0], "truncate (msb0 heuristic): floor(x / 2^k) within one unit");
+    EXPECT(ok[1], "truncate (compare): floor(x / 2^k) within one unit");
+    EXPECT(ok[2], "truncate_msb: floor(x / 2^k) within one unit");
+    EXPECT(ok[3], "truncate_msb0: floor(x / 2^k) within one unit");
+    EXPECT(okr, "truncate_and_reduce exact in the smaller ring");
+  }
+
   // ---- conversions alone: tests/ring_to_field_test.cpp, field_to_ring_test.cpp, ring_extension_test.cpp ----
   {
     std::vector<int64_t> v(n);

@@ -94,6 +94,14 @@ def build():
         lib.mmo_f2r_pre(party, A(y), n, p, 12, A(tmp), A(msb), A(corr))
         lib.mmo_f2r_trunc_post(party, A(tmp), A(msb), A(x), n, p, bw, 12, A(o_))
         out[f"f2r_trunc_party{party}"] = {"tmp": digest(tmp), "msb": digest(msb), "out": digest(o_)}
+    # truncate family (truncation-cheetah.cpp), both parties, signed, with and without the msb0 heuristic
+    aw = splitmix64(SEED + 62, n) & np.uint64((1 << 12) - 1)
+    for party in (1, 2):
+        for heur in (0, 1):
+            adj, cmpv, o_ = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+            lib.mmo_trunc_pre(party, A(x), n, bw, 1, heur, A(adj), A(cmpv))
+            lib.mmo_trunc_post(party, A(adj), A(aw), n, 12, bw, 1, heur, A(o_))
+            out[f"truncate_party{party}_heuristic{heur}"] = {"adj": digest(adj), "cmp": digest(cmpv), "out": digest(o_)}
     return out
 
 

@@ -88,3 +88,18 @@ def test_gpu_reproduces_golden_vectors():
     assert _sha(to_host(oc)) == want["conv_6x14x14_1x1"]["out_cts"]["sha256"]
     assert _sha(to_host(sh)) == want["conv_6x14x14_1x1"]["share"]["sha256"]
     assert _sha(to_host(client.decryptToTensor(oc, meta))) == want["conv_6x14x14_1x1"]["decrypted"]["sha256"]
+    # truncate family against the committed vectors (inputs as make_golden.py seeds them)
+    from openmm_amd.lib import check, dptr, load_library
+    from tests.oracle_binding import splitmix64
+    lib, n, bw = load_library(), 4096, 32
+    x = splitmix64(SEED + 60, n) & np.uint64((1 << bw) - 1)
+    aw = splitmix64(SEED + 62, n) & np.uint64((1 << 12) - 1)
+    d_x, d_aw = to_device(x), to_device(aw)
+    for party in (1, 2):
+        for heur in (0, 1):
+            adj, cmpv, o_ = (torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(3))
+            check(lib.mmh_trunc_pre(party, dptr(d_x), n, bw, 1, heur, dptr(adj), dptr(cmpv), None))
+            check(lib.mmh_trunc_post(party, dptr(adj), dptr(d_aw), n, 12, bw, 1, heur, dptr(o_), None))
+            w = want[f"truncate_party{party}_heuristic{heur}"]
+            assert (_sha(to_host(adj)), _sha(to_host(cmpv)), _sha(to_host(o_))) == \
+                (w["adj"]["sha256"], w["cmp"]["sha256"], w["out"]["sha256"])
