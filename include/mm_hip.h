@@ -442,6 +442,22 @@ int mmh_trunc_post(int party, const uint64_t *d_adj, const uint64_t *d_aw, size_
 int mmh_trunc_reduce_pre(const uint64_t *d_in, size_t n, int shift, uint64_t *d_lower, void *stream);
 int mmh_trunc_reduce_post(const uint64_t *d_in, const uint64_t *d_aw, size_t n, int shift, int bw,
                           uint64_t *d_out, void *stream);
+/* Local share arithmetic of ReLURingProtocol::relu in the USE_CHEETAH build (SCI/src/NonLinear/relu-ring.h):
+ * pre (:216-238) the msb of the share and the operand of millionaire->compare on l-1 bits; post (:244-252,
+ * :308-311) the DReLU share (msb + wrap) % 2 and the selector handed to aux->multiplexer (ALICE flips hers). */
+int mmh_relu_pre(int party, const uint64_t *d_share, size_t n, int l, uint8_t *d_msb, uint64_t *d_cmp, void *stream);
+int mmh_relu_post(int party, const uint8_t *d_msb, const uint8_t *d_wrap, size_t n, uint8_t *d_drelu,
+                  uint8_t *d_sel, void *stream);
+/* AuxProtocols::multiplexer (SCI/src/BuildingBlocks/aux-protocols.cpp:62-93) around its two COTs: the correlation
+ * x * (1 - 2 sel) (:76-78) and y = x * sel + data_R - data_S (:86-88), mod 2^bw_y */
+int mmh_mux_pre(const uint8_t *d_sel, const uint64_t *d_x, size_t n, int bw_y, uint64_t *d_corr, void *stream);
+int mmh_mux_post(const uint8_t *d_sel, const uint64_t *d_x, const uint64_t *d_data_r, const uint64_t *d_data_s,
+                 size_t n, int bw_y, uint64_t *d_y, void *stream);
+/* AuxProtocols::B2A (aux-protocols.cpp:95-126) around its COT: ALICE's correlation -2x (:107-109) and the outputs
+ * x - y (ALICE, :112-114) / x + y (BOB, :119-121) mod 2^bw_y; for bw_y = 1 the bit itself (:97-102, d_y unused) */
+int mmh_b2a_pre(const uint8_t *d_x, size_t n, int bw_y, uint64_t *d_corr, void *stream);
+int mmh_b2a_post(int party, const uint8_t *d_x, const uint64_t *d_y, size_t n, int bw_y, uint64_t *d_out,
+                 void *stream);
 /* out[i] = (out[i] + moduloMult(x[i], y[i], p)) % p : the local cross term that closes
  * CheetahLinear::BOLE (cheetah-api.cpp:648-649; sci::moduloMult utils.hpp:353-363) */
 int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n, uint64_t p,

@@ -143,6 +143,48 @@ __global__ __launch_bounds__(256) void trunc_reduce_kernel(const u64 *__restrict
   out[i] = aw ? ((in[i] >> shift) + aw[i]) & bw_mask(bw - shift) : in[i] & bw_mask(shift);
 }
 
+// ReLURingProtocol::relu of the USE_CHEETAH build (SCI/src/NonLinear/relu-ring.h:216-252, :308-313): msb of the
+// share and the operand of millionaire->compare before it, the DReLU share and the multiplexer's selector after
+__global__ __launch_bounds__(256) void relu_pre_kernel(int party, const u64 *__restrict__ share, size_t n, int l,
+                                                       uint8_t *__restrict__ msb, u64 *__restrict__ cmp) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 cut = (u64(1) << (l - 1)) - 1, v = share[i];
+  msb[i] = (uint8_t)(v >> (l - 1));
+  cmp[i] = party == kAlice ? (v & cut) : cut - (v & cut);
+}
+__global__ __launch_bounds__(256) void relu_post_kernel(int party, const uint8_t *__restrict__ msb,
+                                                        const uint8_t *__restrict__ wrap, size_t n,
+                                                        uint8_t *__restrict__ drelu, uint8_t *__restrict__ sel) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t d = (uint8_t)(((int)msb[i] + (int)wrap[i]) % 2);
+  drelu[i] = d;
+  sel[i] = party == kAlice ? d ^ 1 : d;
+}
+// AuxProtocols::multiplexer (aux-protocols.cpp:62-93): data_r == nullptr gives the COT correlation (:76-78),
+// else the output (:86-88)
+__global__ __launch_bounds__(256) void mux_kernel(const uint8_t *__restrict__ sel, const u64 *__restrict__ x,
+                                                  const u64 *__restrict__ data_r, const u64 *__restrict__ data_s,
+                                                  size_t n, int bw_y, u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 s = sel[i];
+  out[i] = (data_r ? x[i] * s + data_r[i] - data_s[i] : x[i] * (1 - 2 * s)) & bw_mask(bw_y);
+}
+// AuxProtocols::B2A (aux-protocols.cpp:95-126): y == nullptr gives ALICE's correlation -2x (:107-109), else the
+// outputs (:112-114, :119-121; the bit itself for bw_y = 1, :97-102)
+__global__ __launch_bounds__(256) void b2a_kernel(int party, const uint8_t *__restrict__ x,
+                                                  const u64 *__restrict__ y, size_t n, int bw_y, int post,
+                                                  u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 b = x[i], mask = bw_mask(bw_y);
+  if (!post) out[i] = (u64(0) - 2 * b) & mask;
+  else if (bw_y == 1) out[i] = b & 1;
+  else out[i] = (party == kAlice ? b - y[i] : b + y[i]) & mask;
+}
+
 __global__ __launch_bounds__(256) void cross_term_kernel(u64 *__restrict__ out, const u64 *__restrict__ x,
                                                          const u64 *__restrict__ y, size_t n, u64 p, u64 r_hi,
                                                          u64 r_lo) {
@@ -271,6 +313,50 @@ extern "C" int mmh_trunc_reduce_post(const uint64_t *d_in, const uint64_t *d_aw,
   MMH_REQUIRE(n == 0 || (d_in && d_aw && d_out), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(bw >= 2 && bw <= 64 && shift >= 1 && bw - shift > 0, MMH_ERR_INVALID_ARG);
   LAUNCH1D(trunc_reduce_kernel, n, stream, d_in, d_aw, n, shift, bw, d_out);
+  return MMH_OK;
+}
+
+extern "C" int mmh_relu_pre(int party, const uint64_t *d_share, size_t n, int l, uint8_t *d_msb, uint64_t *d_cmp,
+                            void *stream) {
+  MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(n == 0 || (d_share && d_msb && d_cmp), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(l >= 2 && l <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(relu_pre_kernel, n, stream, party, d_share, n, l, d_msb, d_cmp);
+  return MMH_OK;
+}
+extern "C" int mmh_relu_post(int party, const uint8_t *d_msb, const uint8_t *d_wrap, size_t n, uint8_t *d_drelu,
+                             uint8_t *d_sel, void *stream) {
+  MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(n == 0 || (d_msb && d_wrap && d_drelu && d_sel), MMH_ERR_NULL_POINTER);
+  LAUNCH1D(relu_post_kernel, n, stream, party, d_msb, d_wrap, n, d_drelu, d_sel);
+  return MMH_OK;
+}
+extern "C" int mmh_mux_pre(const uint8_t *d_sel, const uint64_t *d_x, size_t n, int bw_y, uint64_t *d_corr,
+                           void *stream) {
+  MMH_REQUIRE(n == 0 || (d_sel && d_x && d_corr), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw_y >= 1 && bw_y <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(mux_kernel, n, stream, d_sel, d_x, (const u64 *)nullptr, (const u64 *)nullptr, n, bw_y, d_corr);
+  return MMH_OK;
+}
+extern "C" int mmh_mux_post(const uint8_t *d_sel, const uint64_t *d_x, const uint64_t *d_data_r,
+                            const uint64_t *d_data_s, size_t n, int bw_y, uint64_t *d_y, void *stream) {
+  MMH_REQUIRE(n == 0 || (d_sel && d_x && d_data_r && d_data_s && d_y), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw_y >= 1 && bw_y <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(mux_kernel, n, stream, d_sel, d_x, d_data_r, d_data_s, n, bw_y, d_y);
+  return MMH_OK;
+}
+extern "C" int mmh_b2a_pre(const uint8_t *d_x, size_t n, int bw_y, uint64_t *d_corr, void *stream) {
+  MMH_REQUIRE(n == 0 || (d_x && d_corr), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw_y >= 1 && bw_y <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(b2a_kernel, n, stream, 1, d_x, (const u64 *)nullptr, n, bw_y, 0, d_corr);
+  return MMH_OK;
+}
+extern "C" int mmh_b2a_post(int party, const uint8_t *d_x, const uint64_t *d_y, size_t n, int bw_y, uint64_t *d_out,
+                            void *stream) {
+  MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(n == 0 || (d_x && d_out && (d_y || bw_y == 1)), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw_y >= 1 && bw_y <= 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(b2a_kernel, n, stream, party, d_x, d_y, n, bw_y, 1, d_out);
   return MMH_OK;
 }
 

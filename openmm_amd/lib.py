@@ -108,6 +108,12 @@ SIGNATURES = {
     "mmh_r2r_pre": [_int, _vp, _sz, _int, _vp, _vp, _vp, _vp],
     "mmh_r2r_post": [_int, _vp, _vp, _vp, _sz, _int, _int, _vp, _vp],
     "mmh_r2r128_post": [_int, _vp, _vp, _vp, _sz, _int, _int, _vp, _vp],
+    "mmh_relu_pre": [_int, _vp, _sz, _int, _vp, _vp, _vp],
+    "mmh_relu_post": [_int, _vp, _vp, _sz, _vp, _vp, _vp],
+    "mmh_mux_pre": [_vp, _vp, _sz, _int, _vp, _vp],
+    "mmh_mux_post": [_vp, _vp, _vp, _vp, _sz, _int, _vp, _vp],
+    "mmh_b2a_pre": [_vp, _sz, _int, _vp, _vp],
+    "mmh_b2a_post": [_int, _vp, _vp, _sz, _int, _vp, _vp],
     "mmh_trunc_pre": [_int, _vp, _sz, _int, _int, _int, _vp, _vp, _vp],
     "mmh_trunc_post": [_int, _vp, _vp, _sz, _int, _int, _int, _int, _vp, _vp],
     "mmh_trunc_reduce_pre": [_vp, _sz, _int, _vp, _vp],

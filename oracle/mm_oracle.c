@@ -705,6 +705,48 @@ void mmo_trunc_reduce_post(const uint64_t *in, const uint64_t *aw, size_t n, int
   for (size_t i = 0; i < n; i++) out[i] = ((in[i] >> shift) + aw[i]) & mask_out;
 }
 
+/* ---- ReLURingProtocol::relu of the USE_CHEETAH build (SCI/src/NonLinear/relu-ring.h:216-252, :308-313):
+ * msb of the share and the operand of millionaire->compare on l-1 bits (ALICE: low l-1 bits, BOB: 2^(l-1)-1 - them) */
+void mmo_relu_pre(int party, const uint64_t *share, size_t n, int l, uint8_t *msb, uint64_t *cmp) {
+  uint64_t cut = (((uint64_t)1) << (l - 1)) - 1;
+  for (size_t i = 0; i < n; i++) {
+    msb[i] = (uint8_t)(share[i] >> (l - 1));
+    uint64_t low = share[i] & cut;
+    cmp[i] = party == ALICE ? low : cut - low;
+  }
+}
+/* :244-252 DReLU share = (msb + wrap) % 2; :308-311 the multiplexer's selector (ALICE flips hers) */
+void mmo_relu_post(int party, const uint8_t *msb, const uint8_t *wrap, size_t n, uint8_t *drelu, uint8_t *sel) {
+  for (size_t i = 0; i < n; i++) {
+    drelu[i] = (uint8_t)((msb[i] + wrap[i]) % 2);
+    sel[i] = party == ALICE ? drelu[i] ^ 1 : drelu[i];
+  }
+}
+/* AuxProtocols::multiplexer (SCI/src/BuildingBlocks/aux-protocols.cpp:62-93): the correlation of its two COTs
+ * (:76-78) and the output from the received and the sent COT strings (:86-88) */
+void mmo_mux_pre(const uint8_t *sel, const uint64_t *x, size_t n, int bw_y, uint64_t *corr) {
+  uint64_t mask = bw_mask(bw_y);
+  for (size_t i = 0; i < n; i++) corr[i] = (x[i] * (1 - 2 * (uint64_t)sel[i])) & mask;
+}
+void mmo_mux_post(const uint8_t *sel, const uint64_t *x, const uint64_t *data_r, const uint64_t *data_s, size_t n,
+                  int bw_y, uint64_t *y) {
+  uint64_t mask = bw_mask(bw_y);
+  for (size_t i = 0; i < n; i++) y[i] = (x[i] * (uint64_t)sel[i] + data_r[i] - data_s[i]) & mask;
+}
+/* AuxProtocols::B2A (aux-protocols.cpp:95-126): ALICE's correlation -2x (:107-109) and both outputs from the COT
+ * string y (:112-114 ALICE x - y, :119-121 BOB x + y); bw_y = 1 is the bit itself (:97-102, y ignored) */
+void mmo_b2a_pre(const uint8_t *x, size_t n, int bw_y, uint64_t *corr) {
+  uint64_t mask = bw_mask(bw_y);
+  for (size_t i = 0; i < n; i++) corr[i] = ((uint64_t)0 - 2 * (uint64_t)x[i]) & mask;
+}
+void mmo_b2a_post(int party, const uint8_t *x, const uint64_t *y, size_t n, int bw_y, uint64_t *out) {
+  uint64_t mask = bw_mask(bw_y);
+  for (size_t i = 0; i < n; i++) {
+    if (bw_y == 1) out[i] = (uint64_t)x[i] & 1;
+    else out[i] = party == ALICE ? ((uint64_t)x[i] - y[i]) & mask : ((uint64_t)x[i] + y[i]) & mask;
+  }
+}
+
 void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, size_t n,
                    int l, uint64_t p, int prime, uint64_t *recv) {
   for (size_t i = 0; i < n; i++) {

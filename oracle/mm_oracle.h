@@ -171,6 +171,15 @@ void mmo_trunc_post(int party, const uint64_t *adj, const uint64_t *aw, size_t n
                     int signed_arith, int heuristic, uint64_t *out);
 void mmo_trunc_reduce_pre(const uint64_t *in, size_t n, int shift, uint64_t *lower);
 void mmo_trunc_reduce_post(const uint64_t *in, const uint64_t *aw, size_t n, int shift, int bw, uint64_t *out);
+/* local arithmetic of ReLURingProtocol::relu (USE_CHEETAH build, relu-ring.h:216-252,:308-313) and of the two
+ * COT-based helpers it and the truncations use: AuxProtocols::multiplexer and B2A (aux-protocols.cpp:62-126) */
+void mmo_relu_pre(int party, const uint64_t *share, size_t n, int l, uint8_t *msb, uint64_t *cmp);
+void mmo_relu_post(int party, const uint8_t *msb, const uint8_t *wrap, size_t n, uint8_t *drelu, uint8_t *sel);
+void mmo_mux_pre(const uint8_t *sel, const uint64_t *x, size_t n, int bw_y, uint64_t *corr);
+void mmo_mux_post(const uint8_t *sel, const uint64_t *x, const uint64_t *data_r, const uint64_t *data_s, size_t n,
+                  int bw_y, uint64_t *y);
+void mmo_b2a_pre(const uint8_t *x, size_t n, int bw_y, uint64_t *corr);
+void mmo_b2a_post(int party, const uint8_t *x, const uint64_t *y, size_t n, int bw_y, uint64_t *out);
 /* ideal COT functionality (silent_ot.h:111-116,198-204; pattern SCI/src/OT/ideal.h:106-156):
  * x = sender randomness (given), receiver gets x + b*corr mod 2^l (l<=64) or mod p (prime=1) */
 void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, size_t n,

@@ -97,6 +97,12 @@ def load():
         lib.mmo_trunc_post.argtypes = [ci, vp, vp, sz, ci, ci, ci, ci, vp]
         lib.mmo_trunc_reduce_pre.argtypes = [vp, sz, ci, vp]
         lib.mmo_trunc_reduce_post.argtypes = [vp, vp, sz, ci, ci, vp]
+        lib.mmo_relu_pre.argtypes = [ci, vp, sz, ci, vp, vp]
+        lib.mmo_relu_post.argtypes = [ci, vp, vp, sz, vp, vp]
+        lib.mmo_mux_pre.argtypes = [vp, vp, sz, ci, vp]
+        lib.mmo_mux_post.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+        lib.mmo_b2a_pre.argtypes = [vp, sz, ci, vp]
+        lib.mmo_b2a_post.argtypes = [ci, vp, vp, sz, ci, vp]
         lib.mmo_ideal_cot.argtypes = [vp, vp, vp, sz, ci, u64, ci, vp]
         lib.mmo_bole_cross_term.argtypes = [vp, vp, vp, sz, u64]
         lib.mmo_ntt_forward_batch.argtypes = [P, vp, sz, sz, ci]
