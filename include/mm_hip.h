@@ -463,6 +463,28 @@ int mmh_b2a_post(int party, const uint8_t *d_x, const uint64_t *d_y, size_t n, i
 int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n, uint64_t p,
                         void *stream);
 
+/* ---- COT post-processing: what SilentOT does between Ferret's output and the values the
+ * conversions above consume.  One launch per side: MITCCRH hash of the Ferret blocks (AES-128 under one fresh
+ * key per element, key_j = seed ^ makeBlock(gid0 + j, 0); emp-tool mitccrh.h at 44b1dde, restated -- that
+ * dependency is absent from the reference tree, so the hash is pinned by FIPS-197 only), then
+ *   prime = 0: SilentOT::send_ot_cam_cc / recv_ot_cam_cc (SCI/src/OT/ferret/silent_ot.h:85-127,:168-207):
+ *              low 64 bits & (2^l - 1), correction, sci::pack_cot_messages / unpack_cot_messages
+ *              (SCI/src/OT/ot-utils.h:154-216) per group of ot_bsize = 8 elements;
+ *   prime = 1: send_ot_cam_cc_prime / recv_ot_cam_cc_prime (silent_ot.h:129-163,:209-242): 128-bit hash mod p,
+ *              correction mod p, ceil(log2 p / 8) bytes per element on the wire.
+ * d_rcm holds n 16-byte blocks in memory order (send_ot_rcm_cc / recv_ot_rcm_cc output, which stay on the
+ * host with Ferret), delta = ferret->Delta, seed = the block `s` the sender draws and sends (silent_ot.h:91-94),
+ * gid0 = the hash's key counter when the call starts; a call advances it by mmh_cot_gids(n) = 8*ceil(n/8)
+ * (every hash<8,H> call renews eight keys).  d_wire: mmh_cot_wire_bytes bytes, 8-byte aligned, exactly the
+ * bytes send_data / recv_data carry after the seed block.  l is ignored when prime = 1, p when prime = 0. */
+int mmh_cot_wire_bytes(size_t n, int l, uint64_t p, int prime, size_t *bytes);
+int mmh_cot_gids(size_t n, uint64_t *gids);
+int mmh_cot_send(const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t seed[2], uint64_t gid0,
+                 const uint64_t *d_corr, size_t n, int l, uint64_t p, int prime, uint64_t *d_data0,
+                 uint8_t *d_wire, void *stream);
+int mmh_cot_recv(const uint64_t *d_rcm, const uint8_t *d_choice, const uint64_t seed[2], uint64_t gid0,
+                 const uint8_t *d_wire, size_t n, int l, uint64_t p, int prime, uint64_t *d_data, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,364 @@
+// Post-processing of the correlated OT on device: SilentOT::send_ot_cam_cc / send_ot_cam_cc_prime /
+// recv_ot_cam_cc / recv_ot_cam_cc_prime (SCI/src/OT/ferret/silent_ot.h:85-242) from the blocks Ferret hands
+// over to data0 / data and the bytes of the correction message, one launch per side: MITCCRH hash (AES-128
+// under one fresh key per element), low 64 bits & mask or 128-bit value mod p, correction, and the wire
+// packing of sci::pack_cot_messages / unpack_cot_messages (SCI/src/OT/ot-utils.h:154-216).  Ferret itself
+// (send/recv_ot_rcm_cc) and the socket stay on the host.
+//
+// AES on CDNA4: one element per lane, key schedule on the fly (a key serves one or two blocks only, so round
+// keys are never stored), SubBytes+MixColumns through one 256-entry table T0[x] = (2s, s, s, 3s) in LDS whose
+// other three rotations are v_alignbit.  The table is kept in 32 interleaved copies, entry x of copy c at
+// word 32x + c with c = lane % 32, so that the 32 lanes an LDS cycle serves always hit 32 different banks
+// whatever bytes they look up (32 KiB per workgroup; workgroups walk the elements grid-stride so the fill is
+// paid once per workgroup).  LDS-bound: 160 lookups per block + 40 per key.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace mmh {
+namespace {
+struct AesT0 {
+  u32 v[256];
+};
+constexpr u32 rotl8(u32 x, int r) { return ((x << r) | (x >> (8 - r))) & 0xff; }
+constexpr u32 xtime(u32 a) { return ((a << 1) ^ ((a & 0x80) ? 0x1b : 0)) & 0xff; }
+// S-box by walking the multiplicative group with generator 3 (p) and its inverse (q); FIPS-197 5.1.1
+constexpr AesT0 make_t0() {
+  AesT0 t{};
+  u32 sbox[256] = {};
+  u32 p = 1, q = 1;
+  do {
+    p = (p ^ xtime(p)) & 0xff;
+    q ^= q << 1;
+    q ^= q << 2;
+    q ^= q << 4;
+    q &= 0xff;
+    if (q & 0x80) q ^= 0x09;
+    sbox[p] = (q ^ rotl8(q, 1) ^ rotl8(q, 2) ^ rotl8(q, 3) ^ rotl8(q, 4)) ^ 0x63;
+  } while (p != 1);
+  sbox[0] = 0x63;
+  for (int x = 0; x < 256; x++) {
+    const u32 s = sbox[x], s2 = xtime(s);
+    t.v[x] = s2 | (s << 8) | (s << 16) | ((s2 ^ s) << 24);
+  }
+  return t;
+}
+__device__ const AesT0 kT0 = make_t0();
+
+constexpr int kCopies = 32;
+constexpr int kCotThreads = 256;
+constexpr int kBatch = 8;  // ot_bsize: elements per hash call and per packed group on the wire
+
+__device__ __forceinline__ u32 rotl(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
+
+struct Aes {
+  const u32 *t;  // LDS table + (lane % 32)
+  __device__ __forceinline__ u32 T(u32 byte) const { return t[byte << 5]; }
+  __device__ __forceinline__ u32 b0(u32 w) const { return w & 0xff; }
+  __device__ __forceinline__ u32 b1(u32 w) const { return (w >> 8) & 0xff; }
+  __device__ __forceinline__ u32 b2(u32 w) const { return (w >> 16) & 0xff; }
+  __device__ __forceinline__ u32 b3(u32 w) const { return w >> 24; }
+  // next round key in place: w[0] ^= SubWord(RotWord(w[3])) ^ rcon, then the running xors
+  __device__ __forceinline__ void next_key(u32 (&w)[4], u32 rcon) const {
+    const u32 x = w[3];
+    const u32 sub = ((T(b1(x)) >> 8) & 0xff) | (T(b2(x)) & 0xff00) | (T(b3(x)) & 0xff0000) |
+                    ((T(b0(x)) << 8) & 0xff000000u);
+    w[0] ^= sub ^ rcon;
+    w[1] ^= w[0];
+    w[2] ^= w[1];
+    w[3] ^= w[2];
+  }
+  __device__ __forceinline__ void round(u32 (&s)[4], const u32 (&k)[4]) const {
+    u32 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      o[c] = T(b0(s[c])) ^ rotl(T(b1(s[(c + 1) & 3])), 8) ^ rotl(T(b2(s[(c + 2) & 3])), 16) ^
+             rotl(T(b3(s[(c + 3) & 3])), 24) ^ k[c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) s[c] = o[c];
+  }
+  __device__ __forceinline__ void last_round(u32 (&s)[4], const u32 (&k)[4]) const {
+    u32 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      o[c] = (((T(b0(s[c])) >> 8) & 0xff) | (T(b1(s[(c + 1) & 3])) & 0xff00) | (T(b2(s[(c + 2) & 3])) & 0xff0000) |
+              ((T(b3(s[(c + 3) & 3])) << 8) & 0xff000000u)) ^
+             k[c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) s[c] = o[c];
+  }
+  // blk[i] = blk[i] ^ AES_key(blk[i]) for NB blocks under one key (MITCCRH::hash)
+  template <int NB>
+  __device__ __forceinline__ void hash(u32 (&key)[4], u32 (&blk)[NB][4]) const {
+    u32 s[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) s[i][c] = blk[i][c] ^ key[c];
+    u32 rcon = 1;
+#pragma unroll
+    for (int r = 1; r <= 10; r++) {
+      next_key(key, rcon);
+      rcon = r == 8 ? 0x1b : rcon << 1;
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        if (r < 10)
+          round(s[i], key);
+        else
+          last_round(s[i], key);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) blk[i][c] ^= s[i][c];
+  }
+};
+
+__device__ __forceinline__ void fill_table(u32 *lds) {
+  for (int i = threadIdx.x; i < 256 * kCopies; i += kCotThreads) lds[i] = kT0.v[i >> 5];
+  __syncthreads();
+}
+
+struct PrimeMod {
+  u64 p, r_hi, r_lo;  // floor(2^128 / p)
+  int bytes;          // ceil(log2 p / 8): bytes per element on the wire (silent_ot.h:139)
+};
+// (hi:lo) mod p.  p < 2^63: Barrett with the exact quotient estimate floor(x*ratio/2^128) >= floor(x/p) - 1;
+// larger p: shift-and-subtract.
+__device__ __forceinline__ u64 mod128(u64 hi, u64 lo, const PrimeMod &m) {
+  if (m.p >> 63) {
+    u64 r = hi >= m.p ? hi - m.p : hi;
+    for (int i = 63; i >= 0; --i) {
+      const u64 top = r >> 63;
+      r = (r << 1) | ((lo >> i) & 1);
+      if (top | (r >= m.p)) r -= m.p;
+    }
+    return r;
+  }
+  return barrett128(hi, lo, m.p, m.r_hi, m.r_lo);
+}
+
+__device__ __forceinline__ u64 words64(u32 lo, u32 hi) { return make64(lo, hi); }
+
+// Sender.  rcm [n] blocks; element j is hashed under key S ^ (gid0 + j in the high half).
+// Ring: wire holds, per group of 8 elements, ceil(8*l/64) words (a ragged last group ceil(rem*l/64)).
+// Prime: wire holds `bytes` bytes per element, back to back.
+template <bool PRIME>
+__global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__restrict__ rcm, uint4 delta, uint4 S,
+                                                                u64 gid0, const u64 *__restrict__ corr, size_t n,
+                                                                int l, PrimeMod pm, u64 *__restrict__ data0,
+                                                                uint8_t *__restrict__ wire) {
+  __shared__ u32 table[256 * kCopies];
+  __shared__ u64 stage[kCotThreads];
+  fill_table(table);
+  const Aes aes{table + (threadIdx.x & (kCopies - 1))};
+  const u64 mask = l >= 64 ? ~u64(0) : (u64(1) << l) - 1;
+  const int wpg = (kBatch * l + 63) / 64;  // words per full group
+  const size_t n_chunks = (n + kCotThreads - 1) / kCotThreads;
+  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const size_t base = chunk * kCotThreads, j = base + threadIdx.x;
+    const int live = (int)min((size_t)kCotThreads, n - base);
+    u64 cd = 0;
+    if (j < n) {
+      const uint4 r = rcm[j];
+      const u64 gid = gid0 + j;
+      u32 key[4] = {S.x, S.y, S.z ^ lo32(gid), S.w ^ hi32(gid)};
+      u32 blk[2][4] = {{r.x, r.y, r.z, r.w}, {r.x ^ delta.x, r.y ^ delta.y, r.z ^ delta.z, r.w ^ delta.w}};
+      aes.hash<2>(key, blk);
+      const u64 c = corr[j];
+      if (PRIME) {  // silent_ot.h:153-156
+        const u64 t0 = mod128(words64(blk[0][2], blk[0][3]), words64(blk[0][0], blk[0][1]), pm);
+        const u64 t1 = mod128(words64(blk[1][2], blk[1][3]), words64(blk[1][0], blk[1][1]), pm);
+        data0[j] = t0;
+        // (t0 + t1 + corr) % p over 128 bits: corr is any 64-bit value
+        const u64 s = t0 + t1, lo = s + c;
+        const u64 hi = (u64)(s < t0) + (u64)(lo < s);
+        cd = mod128(hi, lo, pm);
+      } else {  // silent_ot.h:112-115
+        const u64 d0 = words64(blk[0][0], blk[0][1]) & mask;
+        data0[j] = d0;
+        cd = (c + d0 + words64(blk[1][0], blk[1][1])) & mask;
+      }
+    }
+    __syncthreads();  // previous chunk's readers are done with stage
+    stage[threadIdx.x] = cd;
+    __syncthreads();
+    if (PRIME) {
+      // live*bytes bytes starting at base*bytes (a multiple of 4): whole 32-bit words, then the last bytes
+      const int nbytes = live * pm.bytes;
+      uint8_t *dst = wire + base * (size_t)pm.bytes;
+      const uint8_t *sb = reinterpret_cast<const uint8_t *>(stage);
+      for (int w = threadIdx.x; w < (nbytes + 3) / 4; w += kCotThreads) {
+        u32 word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int byte = 4 * w + k;
+          if (byte < nbytes) {
+            const int e = byte / pm.bytes, o = byte - e * pm.bytes;
+            word |= (u32)sb[8 * e + o] << (8 * k);
+          }
+        }
+        if (4 * w + 4 <= nbytes) {
+          reinterpret_cast<u32 *>(dst)[w] = word;
+        } else {
+          for (int k = 0; 4 * w + k < nbytes; k++) dst[4 * w + k] = (uint8_t)(word >> (8 * k));
+        }
+      }
+    } else {
+      // ot-utils.h:154-186: word w of group g gathers the elements whose l bits overlap [64w, 64w+64)
+      const int groups = (live + kBatch - 1) / kBatch;
+      u64 *dst = reinterpret_cast<u64 *>(wire) + (base / kBatch) * (size_t)wpg;
+      for (int t = threadIdx.x; t < groups * wpg; t += kCotThreads) {
+        const int g = t / wpg, w = t - g * wpg;
+        const int bs = min(kBatch, live - g * kBatch);
+        if (w >= (bs * l + 63) / 64) continue;  // ragged last group is shorter
+        u64 word = 0;
+        const int first = (64 * w) / l;
+        for (int i = first; i < bs && i * l < 64 * w + 64; i++) {
+          const u64 v = stage[g * kBatch + i];
+          const int start = i * l - 64 * w;  // bit position of the element relative to this word
+          word ^= start >= 0 ? v << start : v >> (-start);
+        }
+        dst[(size_t)g * wpg + w] = word;
+      }
+    }
+  }
+}
+
+// Receiver.  rcm [n] blocks (its own), b [n] choice bits as bytes.
+template <bool PRIME>
+__global__ __launch_bounds__(kCotThreads) void cot_recv_kernel(const uint4 *__restrict__ rcm,
+                                                                const uint8_t *__restrict__ b, uint4 S, u64 gid0,
+                                                                const uint8_t *__restrict__ wire, size_t n, int l,
+                                                                PrimeMod pm, u64 *__restrict__ data) {
+  __shared__ u32 table[256 * kCopies];
+  fill_table(table);
+  const Aes aes{table + (threadIdx.x & (kCopies - 1))};
+  const u64 mask = l >= 64 ? ~u64(0) : (u64(1) << l) - 1;
+  const int wpg = (kBatch * l + 63) / 64;
+  const size_t n_chunks = (n + kCotThreads - 1) / kCotThreads;
+  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const size_t j = chunk * kCotThreads + threadIdx.x;
+    if (j >= n) continue;
+    const uint4 r = rcm[j];
+    const u64 gid = gid0 + j;
+    u32 key[4] = {S.x, S.y, S.z ^ lo32(gid), S.w ^ hi32(gid)};
+    u32 blk[1][4] = {{r.x, r.y, r.z, r.w}};
+    aes.hash<1>(key, blk);
+    const bool choice = b[j] != 0;
+    if (PRIME) {  // silent_ot.h:227-239
+      u64 c = 0;
+      const uint8_t *src = wire + j * (size_t)pm.bytes;
+      for (int k = 0; k < pm.bytes; k++) c |= (u64)src[k] << (8 * k);
+      const u64 t = mod128(words64(blk[0][2], blk[0][3]), words64(blk[0][0], blk[0][1]), pm);
+      u64 out = t;
+      if (choice) {  // (c + (p - t)) % p over 128 bits: c is whatever the wire held
+        const u64 d = pm.p - t, lo = c + d;
+        out = mod128((u64)(lo < c), lo, pm);
+      }
+      data[j] = out;
+    } else {  // ot-utils.h:188-216, silent_ot.h:198-204
+      const u64 h = words64(blk[0][0], blk[0][1]);
+      const u64 *grp = reinterpret_cast<const u64 *>(wire) + (j / kBatch) * (size_t)wpg;
+      const int start = (int)(j % kBatch) * l, sb = start >> 6, eb = (start + l - 1) >> 6, sh = start & 63;
+      u64 c = grp[sb] >> sh;
+      if (eb != sb) c ^= grp[eb] << (64 - sh);
+      data[j] = (choice ? c - h : h) & mask;
+    }
+  }
+}
+
+int prime_bytes(u64 p) {
+  int bits = 0;
+  while (bits < 64 && (p >> bits) > 1) bits++;
+  if (p & (p - 1)) bits++;
+  return (bits + 7) / 8;
+}
+PrimeMod make_prime(u64 p) {
+  PrimeMod m{};
+  m.p = p;
+  if (p >= 2) {
+    using u128 = unsigned __int128;
+    const u128 ratio = p & (p - 1) ? ~(u128)0 / p : (~(u128)0 / p) + 1;
+    m.r_hi = (u64)(ratio >> 64);
+    m.r_lo = (u64)ratio;
+    m.bytes = prime_bytes(p);
+  }
+  return m;
+}
+unsigned cot_grid(size_t n) {
+  const size_t chunks = (n + kCotThreads - 1) / kCotThreads;
+  return (unsigned)std::min<size_t>(chunks, 256 * 4);  // 4 workgroups of 32 KiB LDS per CU
+}
+uint4 as_block(const uint64_t v[2]) { return uint4{(u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32)}; }
+}  // namespace
+}  // namespace mmh
+
+using namespace mmh;
+
+extern "C" int mmh_cot_wire_bytes(size_t n, int l, uint64_t p, int prime, size_t *bytes) {
+  MMH_REQUIRE(bytes, MMH_ERR_NULL_POINTER);
+  if (prime) {
+    MMH_REQUIRE(p >= 2, MMH_ERR_INVALID_ARG);
+    *bytes = n * (size_t)prime_bytes(p);
+    return MMH_OK;
+  }
+  MMH_REQUIRE(l >= 1 && l <= 64, MMH_ERR_INVALID_ARG);
+  const size_t full = n / kBatch, rem = n % kBatch;
+  *bytes = 8 * (full * (size_t)((kBatch * l + 63) / 64) + (rem * (size_t)l + 63) / 64);
+  return MMH_OK;
+}
+
+extern "C" int mmh_cot_gids(size_t n, uint64_t *gids) {
+  MMH_REQUIRE(gids, MMH_ERR_NULL_POINTER);
+  *gids = kBatch * (uint64_t)((n + kBatch - 1) / kBatch);
+  return MMH_OK;
+}
+
+static int cot_check(size_t n, int l, uint64_t p, int prime) {
+  MMH_REQUIRE(n <= ((size_t)1 << 40), MMH_ERR_OUT_BOUND);
+  if (prime)
+    MMH_REQUIRE(p >= 2, MMH_ERR_INVALID_ARG);
+  else
+    MMH_REQUIRE(l >= 1 && l <= 64, MMH_ERR_INVALID_ARG);
+  return MMH_OK;
+}
+
+extern "C" int mmh_cot_send(const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t seed[2], uint64_t gid0,
+                            const uint64_t *d_corr, size_t n, int l, uint64_t p, int prime, uint64_t *d_data0,
+                            uint8_t *d_wire, void *stream) {
+  MMH_REQUIRE(delta && seed, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(n == 0 || (d_rcm && d_corr && d_data0 && d_wire), MMH_ERR_NULL_POINTER);
+  if (int rc = cot_check(n, l, p, prime)) return rc;
+  if (n == 0) return MMH_OK;
+  const PrimeMod pm = make_prime(prime ? p : 2);
+  const dim3 grid(cot_grid(n)), block(kCotThreads);
+  if (prime)
+    hipLaunchKernelGGL(cot_send_kernel<true>, grid, block, 0, (hipStream_t)stream, (const uint4 *)d_rcm,
+                       as_block(delta), as_block(seed), gid0, d_corr, n, 64, pm, d_data0, d_wire);
+  else
+    hipLaunchKernelGGL(cot_send_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint4 *)d_rcm,
+                       as_block(delta), as_block(seed), gid0, d_corr, n, l, pm, d_data0, d_wire);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+extern "C" int mmh_cot_recv(const uint64_t *d_rcm, const uint8_t *d_choice, const uint64_t seed[2], uint64_t gid0,
+                            const uint8_t *d_wire, size_t n, int l, uint64_t p, int prime, uint64_t *d_data,
+                            void *stream) {
+  MMH_REQUIRE(seed, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(n == 0 || (d_rcm && d_choice && d_wire && d_data), MMH_ERR_NULL_POINTER);
+  if (int rc = cot_check(n, l, p, prime)) return rc;
+  if (n == 0) return MMH_OK;
+  const PrimeMod pm = make_prime(prime ? p : 2);
+  const dim3 grid(cot_grid(n)), block(kCotThreads);
+  if (prime)
+    hipLaunchKernelGGL(cot_recv_kernel<true>, grid, block, 0, (hipStream_t)stream, (const uint4 *)d_rcm, d_choice,
+                       as_block(seed), gid0, d_wire, n, 64, pm, d_data);
+  else
+    hipLaunchKernelGGL(cot_recv_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint4 *)d_rcm, d_choice,
+                       as_block(seed), gid0, d_wire, n, l, pm, d_data);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}

@@ -119,6 +119,10 @@ SIGNATURES = {
     "mmh_trunc_reduce_pre": [_vp, _sz, _int, _vp, _vp],
     "mmh_trunc_reduce_post": [_vp, _vp, _sz, _int, _int, _vp, _vp],
     "mmh_bole_cross_term": [_vp, _vp, _vp, _sz, _u64, _vp],
+    "mmh_cot_wire_bytes": [_sz, _int, _u64, _int, C.POINTER(_sz)],
+    "mmh_cot_gids": [_sz, C.POINTER(_u64)],
+    "mmh_cot_send": [_vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _int, _u64, _int, _vp, _vp, _vp],
+    "mmh_cot_recv": [_vp, _vp, C.POINTER(_u64), _u64, _vp, _sz, _int, _u64, _int, _vp, _vp],
 }
 
 

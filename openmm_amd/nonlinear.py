@@ -25,6 +25,8 @@ class AuxProtocols:
 
     def _dev(self, a):
         import torch
+        if isinstance(a, torch.Tensor):   # an on-device COT (silent_ot.SilentOT) already returns device tensors
+            return a
         a = np.ascontiguousarray(a)
         return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(f"cuda:{self.device}")
 

@@ -122,6 +122,10 @@ class Truncation:
 
     def _cot(self, msb, corr, dim, l=None, p=None):
         """the one interactive step (host): returns y as a device tensor"""
+        if getattr(self.cot, "on_device", False):   # silent_ot.SilentOT: operands and result stay on the device
+            if self.party == ALICE:
+                return self.cot.send_cot_prime(corr, dim, p) if p else self.cot.send_cot(corr, dim, l)
+            return self.cot.recv_cot_prime(msb, dim, p) if p else self.cot.recv_cot(msb, dim, l)
         if self.party == ALICE:
             c = L.to_host(corr)
             y = self.cot.send_cot_prime(c, dim, p) if p else self.cot.send_cot(c, dim, l)

@@ -188,6 +188,18 @@ void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, si
 uint64_t mmo_modulo_mult(uint64_t a, uint64_t b, uint64_t mod);
 void mmo_bole_cross_term(uint64_t *out, const uint64_t *x, const uint64_t *y, size_t n, uint64_t p);
 
+/* ---- COT post-processing (mm_cot_oracle.c): SilentOT::send/recv_ot_cam_cc[_prime], silent_ot.h:85-242 ----
+ * AES-128 per FIPS-197; MITCCRH<8> restated from emp-tool 44b1dde [upstream-recall, parity unpinned] */
+void mmo_aes128_expand(const uint8_t key[16], uint8_t rk[176]);
+void mmo_aes128_encrypt(const uint8_t rk[176], const uint8_t in[16], uint8_t out[16]);
+void mmo_mitccrh_hash(const uint64_t S[2], uint64_t gid0, const uint64_t *blocks, size_t n, int H, uint64_t *out);
+uint64_t mmo_cot_gids(size_t n);
+size_t mmo_cot_wire_bytes(size_t n, int l, uint64_t p, int prime);
+void mmo_cot_send(const uint64_t *rcm, const uint64_t delta[2], const uint64_t S[2], uint64_t gid0,
+                  const uint64_t *corr, size_t n, int l, uint64_t p, int prime, uint64_t *data0, uint8_t *wire);
+void mmo_cot_recv(const uint64_t *rcm, const uint8_t *b, const uint64_t S[2], uint64_t gid0, const uint8_t *wire,
+                  size_t n, int l, uint64_t p, int prime, uint64_t *data);
+
 /* ---- tensor <-> polynomial geometry (mm_geom_oracle.c) ---- */
 int  mmo_conv_out_shape(const long ishape[3], const long fshape[3], int same, int stride, long out_hw[2]);
 int  mmo_conv_shape_infer(long N, const long ishape[3], const long fshape[3], int same, int stride,

@@ -105,6 +105,15 @@ def load():
         lib.mmo_b2a_post.argtypes = [ci, vp, vp, sz, ci, vp]
         lib.mmo_ideal_cot.argtypes = [vp, vp, vp, sz, ci, u64, ci, vp]
         lib.mmo_bole_cross_term.argtypes = [vp, vp, vp, sz, u64]
+        lib.mmo_aes128_expand.argtypes = [vp, vp]
+        lib.mmo_aes128_encrypt.argtypes = [vp, vp, vp]
+        lib.mmo_mitccrh_hash.argtypes = [vp, u64, vp, sz, ci, vp]
+        lib.mmo_cot_gids.argtypes = [sz]
+        lib.mmo_cot_gids.restype = u64
+        lib.mmo_cot_wire_bytes.argtypes = [sz, ci, u64, ci]
+        lib.mmo_cot_wire_bytes.restype = sz
+        lib.mmo_cot_send.argtypes = [vp, vp, vp, u64, vp, sz, ci, u64, ci, vp, vp]
+        lib.mmo_cot_recv.argtypes = [vp, vp, vp, u64, vp, sz, ci, u64, ci, vp]
         lib.mmo_ntt_forward_batch.argtypes = [P, vp, sz, sz, ci]
         lib.mmo_ntt_inverse_batch.argtypes = [P, vp, sz, sz, ci]
         lib.mmo_conv_mac_reference.argtypes = [P, vp, vp, sz, sz, sz, vp, ci]
