@@ -123,6 +123,33 @@ def conversion_leg(torch, openmm_amd):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     res.update({"truncate_1e7_pre_post_us": us, "truncate_hbm_frac": 48.0 * n / (us * 1e-6) / HBM_PEAK})
+    # COT post-processing of the same 10^7 elements (silent_ot.h:129-163,:209-242, mod p): the sender's launch
+    # hashes two blocks per element, the receiver's one; blocks, choices and the wire resident in HBM
+    import ctypes as C
+    rcm = torch.randint(-(1 << 62), 1 << 62, (n, 2), dtype=torch.int64, device="cuda", generator=gen)
+    choice = (x & 1).to(torch.uint8)
+    two = (C.c_uint64 * 2)
+    delta, seed = two(0x0123456789ABCDEF, 0xFEDCBA9876543211), two(0x1122334455667788, 0x99AABBCCDDEEFF00)
+    for prime, key in ((1, "prime"), (0, "ring")):
+        nb = C.c_size_t()
+        L.check(lib.mmh_cot_wire_bytes(n, l, p, prime, C.byref(nb)))
+        wire = torch.empty((nb.value + 7) // 8, dtype=torch.int64, device="cuda")
+
+        def cot():
+            L.check(lib.mmh_cot_send(L.dptr(rcm), delta, seed, 0, L.dptr(corr), n, l, p, prime, L.dptr(tmp),
+                                     L.dptr(wire), s))
+            L.check(lib.mmh_cot_recv(L.dptr(rcm), L.dptr(choice), seed, 0, L.dptr(wire), n, l, p, prime, L.dptr(out),
+                                     s))
+        cot()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            cot()
+        e1.record()
+        torch.cuda.synchronize()
+        res[f"cot_{key}_1e7_send_recv_us"] = e0.elapsed_time(e1) / 10 * 1e3
+    # three AES-128 encryptions + two key schedules per element pair of launches
+    res["cot_aes_blocks_per_s"] = 3.0 * n / (res["cot_prime_1e7_send_recv_us"] * 1e-6)
     return res
 
 

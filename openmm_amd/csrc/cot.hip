@@ -46,10 +46,14 @@ constexpr AesT0 make_t0() {
 __device__ const AesT0 kT0 = make_t0();
 
 constexpr int kCopies = 32;
-constexpr int kCotThreads = 256;
+constexpr int kCotThreads = 512;
 constexpr int kBatch = 8;  // ot_bsize: elements per hash call and per packed group on the wire
 
 __device__ __forceinline__ u32 rotl(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
+// hipcc leaves a five-term xor as four v_xor_b32
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // v_bitop3_b32 with the truth table of a ^ b ^ c
+}
 
 struct Aes {
   const u32 *t;  // LDS table + (lane % 32)
@@ -72,8 +76,8 @@ struct Aes {
     u32 o[4];
 #pragma unroll
     for (int c = 0; c < 4; c++)
-      o[c] = T(b0(s[c])) ^ rotl(T(b1(s[(c + 1) & 3])), 8) ^ rotl(T(b2(s[(c + 2) & 3])), 16) ^
-             rotl(T(b3(s[(c + 3) & 3])), 24) ^ k[c];
+      o[c] = xor3(xor3(T(b0(s[c])), rotl(T(b1(s[(c + 1) & 3])), 8), rotl(T(b2(s[(c + 2) & 3])), 16)),
+                  rotl(T(b3(s[(c + 3) & 3])), 24), k[c]);
 #pragma unroll
     for (int c = 0; c < 4; c++) s[c] = o[c];
   }
@@ -289,7 +293,7 @@ PrimeMod make_prime(u64 p) {
 }
 unsigned cot_grid(size_t n) {
   const size_t chunks = (n + kCotThreads - 1) / kCotThreads;
-  return (unsigned)std::min<size_t>(chunks, 256 * 4);  // 4 workgroups of 32 KiB LDS per CU
+  return (unsigned)std::min<size_t>(chunks, 256 * 4);  // up to 4 workgroups of 34 KiB LDS per CU
 }
 uint4 as_block(const uint64_t v[2]) { return uint4{(u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32)}; }
 }  // namespace

@@ -12,6 +12,7 @@
 
 #include "mm_gemini/cheetah_linear.h"
 #include "mm_gemini/library.h"
+#include "mm_gemini/silent_ot.h"
 #include "mm_gemini/truncation.h"
 
 using gemini::CheetahLinear;
@@ -203,6 +204,44 @@ int main(int argc, char **argv) {
     EXPECT(r2f, "ring_to_field exact (ring_to_field_test.cpp:128-143)");
     EXPECT(f2r, "field_to_ring exact (field_to_ring_test.cpp:121-135)");
     EXPECT(ext, "ring_to_ring128 32 -> 96 bits exact (ring_extension_test.cpp:100-119)");
+  }
+
+  // ---- the same conversions over mm::SilentOT: device COT post-processing (silent_ot.h:85-242) on an ideal
+  // Ferret, correction bytes through the loop-back channel ---------------------------------------------------
+  {
+    auto fbox = std::make_shared<mm::IdealFerret::Mailbox>();
+    mm::IdealFerret fA(fbox, 11), fB(fbox, 12);
+    auto cio = mm::LoopbackIO::MakePair();
+    mm::SilentOT otA(&fA, cio.first.get(), 21), otB(&fB, cio.second.get(), 22);
+    mm::Truncation tA(1, &otA), tB(2, &otB);
+    std::vector<int64_t> v(n);
+    std::vector<u64> s[2], f[2], r[2], e[2];
+    for (int q = 0; q < 2; ++q) s[q].resize(n), f[q].resize(n), r[q].resize(n), e[q].resize(n);
+    for (int i = 0; i < n; ++i) {
+      v[i] = (int64_t)(rng() % (1ULL << (bw - 2))) - (1LL << (bw - 3));
+      s[0][i] = rng() & mask, s[1][i] = ((u64)v[i] - s[0][i]) & mask;
+    }
+    both(A, B, [&](Party &p) {
+      const int q = p.id - 1;
+      mm::Truncation &t = q ? tB : tA;
+      t.ring_to_field(n, s[q].data(), f[q].data(), bw, prime);
+      for (int i = 0; i < n; ++i) f[q][i] %= prime;
+      t.field_to_ring(n, f[q].data(), r[q].data(), prime, bw);
+      t.ring_to_ring(n, s[q].data(), e[q].data(), bw, 64);
+    });
+    bool r2f = true, f2r = true, ext = true;
+    for (int i = 0; i < n; ++i) {
+      r2f &= (f[0][i] + f[1][i]) % prime == (u64)((v[i] % (int64_t)prime + (int64_t)prime) % (int64_t)prime);
+      f2r &= to_signed(r[0][i] + r[1][i], bw) == v[i];
+      ext &= (int64_t)(e[0][i] + e[1][i]) == v[i];
+    }
+    EXPECT(r2f, "ring_to_field over SilentOT (device hash + correction mod p) exact");
+    EXPECT(f2r, "field_to_ring over SilentOT (mod 2^32, packed wire) exact");
+    EXPECT(ext, "ring_to_ring 32 -> 64 over SilentOT exact");
+    const u64 g = 8 * (((u64)n + 7) / 8);
+    EXPECT(otA.gid == 3 * g && otB.gid == 3 * g, "hash key counter advances by 8*ceil(n/8) per call on both sides");
+    const u64 expect_bytes = 3 * 16 + (u64)n * 4 + (u64)(n / 8) * 8 * 4 + (u64)(n / 8) * 8 * 4;
+    EXPECT(n % 8 != 0 || cio.first->counter == expect_bytes, "wire bytes: seed + 4 B (mod p), 32 b and 32 b per element");
   }
 
   // ---- HomConv and HomFC over a 2^37 ring (shipped ell=37, scripts/common.sh:48-56) ----------------

@@ -102,6 +102,11 @@ def build():
             lib.mmo_trunc_pre(party, A(x), n, bw, 1, heur, A(adj), A(cmpv))
             lib.mmo_trunc_post(party, A(adj), A(aw), n, 12, bw, 1, heur, A(o_))
             out[f"truncate_party{party}_heuristic{heur}"] = {"adj": digest(adj), "cmp": digest(cmpv), "out": digest(o_)}
+    # COT post-processing (silent_ot.h:85-242): both sides, mod 2^37 and mod p, ragged length, gid offset 40
+    from tests.test_cot_oracle import cot_pair
+    for name, l_, p_ in (("ring37", 37, 0), ("prime", 0, 4293918721)):
+        data0, data, _, _, wire, _ = cot_pair(lib, 4099, l_, p_, SEED + 80, gid0=40)
+        out[f"cot_{name}"] = {"data0": digest(data0), "wire": digest(wire), "data": digest(data)}
     return out
 
 

@@ -103,3 +103,11 @@ def test_gpu_reproduces_golden_vectors():
             w = want[f"truncate_party{party}_heuristic{heur}"]
             assert (_sha(to_host(adj)), _sha(to_host(cmpv)), _sha(to_host(o_))) == \
                 (w["adj"]["sha256"], w["cmp"]["sha256"], w["out"]["sha256"])
+    # COT post-processing: the sender's data0 and wire, the receiver's data from that wire
+    import ctypes as C
+    from tests.test_cot_gpu import gpu_pair
+    for name, l_, p_ in (("ring37", 37, 0), ("prime", 0, 4293918721)):
+        _, (g_data0, g_wire, g_data) = gpu_pair(4099, l_, p_, SEED + 80, 40)
+        w = want[f"cot_{name}"]
+        assert (_sha(g_data0), _sha(g_wire), _sha(g_data)) == \
+            (w["data0"]["sha256"], w["wire"]["sha256"], w["data"]["sha256"])
