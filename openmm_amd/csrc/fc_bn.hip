@@ -6,6 +6,10 @@
 #include "geometry.hpp"
 
 namespace mmh {
+int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
+                        const int64_t *d_u, const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep,
+                        size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane,
+                        u64 *d_share_out);
 int launch_share_from_mask(const mmh_ctx *ctx, const u64 *r, u64 *out, size_t groups, size_t n_targets,
                            size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
                            hipStream_t s);
@@ -218,31 +222,36 @@ static int fc_server_impl(const mmh_fc_plan *p, const uint64_t *d_in_cts, const 
     cts = (const u64 *)input;
   }
   if (!rc && scratch_alloc(&acc, p->n_out * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
-  if (!rc && scratch_alloc(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   // :443-457: out[j] = sum_i input[i] * matrix[j][i]
   if (!rc)
     rc = mmh_mul_plain_acc(ctx, 0, cts, p->n_in, d_weight_pts, p->n_out * p->n_in, p->n_out, 1, p->n_in, 1, 0,
                            p->n_in, 1, 0, (u64 *)acc, stream);
   // addRandomMask :487-517 (the output vector is sized once, not per worker as the reference does);
   // the two re-sharing builds differ as in HomConv2DSS (hom_conv2d_ss.cc:179-273, :323-328, :358-380)
-  if (!rc && exact) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
-  if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
-  if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
-  if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
-  if (!rc && !exact) rc = mmh_sub_rns_poly(ctx, 1, d_out_cts, d_mask, p->n_out, stream);
-  if (!rc && !exact)
-    rc = launch_share_from_mask(ctx, d_mask, d_out_share, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
-                                p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  if (!rc && !exact) {
+    // shipped build: the fused tail of bfv.hip (forward NTT of u, inverse NTT of u * pk, one finishing pass) gives
+    // the bits of the step-by-step sequence below in 3 launches instead of 9; the share comes from the mask alone
+    rc = reshare_tail_approx(ctx, (u64 *)acc, false, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, p->n_out,
+                             d_out_cts, s, nullptr, 0, nullptr);
+    if (!rc)
+      rc = launch_share_from_mask(ctx, d_mask, d_out_share, 1, p->n_targets, p->n_out, (size_t)p->meta.rows,
+                                  p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+  }
   if (exact) {
+    if (!rc) rc = mmh_flood_add(ctx, (u64 *)acc, d_flood, p->n_out, stream);
+    if (!rc) rc = mmh_mod_switch_to_last(ctx, (const u64 *)acc, p->n_out, d_out_cts, stream);
+    if (!rc && scratch_alloc(&zero, p->n_out * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+    if (!rc) rc = mmh_encrypt_zero_asym(ctx, 1, d_pk_ntt_last, d_u, d_e0, d_e1, p->n_out, (u64 *)zero, stream);
+    if (!rc) rc = mmh_ct_add(ctx, 1, d_out_cts, (const u64 *)zero, p->n_out, stream);
     if (!rc && scratch_alloc(&mask_t, p->n_out * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
     if (!rc) rc = mmh_reduce_mod_t(ctx, d_mask, (u64 *)mask_t, p->n_out * N, stream);
     if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)mask_t, p->n_out, 1, d_out_cts, stream);
     if (!rc)
       rc = launch_gather_targets(ctx, (const u64 *)mask_t, d_out_share, 1, p->n_targets, p->n_out,
                                  (size_t)p->meta.rows, p->d_tgt_coef, p->d_tgt_dst, p->d_tgt_slice, s);
+    // truncate_for_decryption :462-466 + removeUnusedCoeffs :525-561
+    if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, p->n_out, stream);
   }
-  // truncate_for_decryption :462-466 + removeUnusedCoeffs :525-561
-  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, p->n_out, p->d_keep, p->n_out, stream);
   if (input) (void)scratch_free(input, s);
   if (acc) (void)scratch_free(acc, s);
   if (zero) (void)scratch_free(zero, s);
