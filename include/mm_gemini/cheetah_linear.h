@@ -9,22 +9,13 @@
 #include <vector>
 
 #include "mm_gemini/core.h"
+#include "mm_gemini/hom_conv2d_ss.h"
 #include "mm_gemini/io.h"
 
 struct mmh_ctx;
 
 namespace gemini {
 
-struct HomConv2DSS {
-  struct Meta {  // include/gemini/cheetah/hom_conv2d_ss.h:35-42
-    TensorShape ishape;
-    TensorShape fshape;
-    size_t n_filters;
-    Padding padding;
-    size_t stride;
-    bool is_shared_input;
-  };
-};
 struct HomFCSS {
   struct Meta {  // hom_fc_ss.h:34-38
     TensorShape input_shape;

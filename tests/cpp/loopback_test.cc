@@ -16,6 +16,7 @@
 #include "mm_gemini/truncation.h"
 
 using gemini::CheetahLinear;
+using gemini::Code;
 using gemini::Padding;
 using gemini::Tensor;
 using gemini::TensorShape;
@@ -242,6 +243,66 @@ int main(int argc, char **argv) {
     EXPECT(otA.gid == 3 * g && otB.gid == 3 * g, "hash key counter advances by 8*ceil(n/8) per call on both sides");
     const u64 expect_bytes = 3 * 16 + (u64)n * 4 + (u64)(n / 8) * 8 * 4 + (u64)(n / 8) * 8 * 4;
     EXPECT(n % 8 != 0 || cio.first->counter == expect_bytes, "wire bytes: seed + 4 B (mod p), 32 b and 32 b per element");
+  }
+
+  // ---- gemini::HomConv2DSS class surface (hom_conv2d_ss.h:27-84), driven the way cheetah-api.cpp:332-445 does ----
+  {
+    const int l = 37;
+    const u64 t37 = 1ULL << l, m37 = t37 - 1;
+    mm::he::Context hctx(4096, {60, 49}, t37);
+    mm::he::SecretKey sk;
+    auto pk = std::make_shared<mm::he::PublicKey>();
+    mm::he::GenerateKeys(hctx, sk, *pk);
+    gemini::HomConv2DSS client, server, nokeys;
+    EXPECT(client.setUp(hctx, sk) == Code::OK && server.setUp(hctx, std::nullopt, pk) == Code::OK, "HomConv2DSS::setUp");
+    EXPECT(server.poly_degree() == 4096 && server.plain_modulus() == t37, "poly_degree / plain_modulus");
+    mm::he::SecretKey bad;
+    bad.data.resize(5);
+    EXPECT(nokeys.setUp(hctx, bad) == Code::ERR_INVALID_ARG, "setUp rejects a key of another context");
+    EXPECT(nokeys.setUp(hctx) == Code::OK, "setUp without keys");
+    gemini::HomConv2DSS::Meta meta{TensorShape({5, 13, 13}), TensorShape({5, 3, 3}), 3, Padding::SAME, 2, true};
+    Tensor<u64> x(meta.ishape), s0(meta.ishape), s1(meta.ishape);
+    for (int i = 0; i < 5 * 13 * 13; ++i) {
+      x.data()[i] = (u64)((int64_t)(rng() % (1 << 13)) - (1 << 12)) & m37;
+      s0.data()[i] = rng() & m37, s1.data()[i] = (x.data()[i] - s0.data()[i]) & m37;
+    }
+    std::vector<Tensor<u64>> filters(3, Tensor<u64>(meta.fshape));
+    for (auto &f : filters)
+      for (int i = 0; i < 45; ++i) f.data()[i] = (u64)((int64_t)(rng() % (1 << 13)) - (1 << 12)) & m37;
+    std::vector<mm::he::Ciphertext> enc, out_ct;
+    std::vector<mm::he::Plaintext> share_pts;
+    std::vector<std::vector<mm::he::Plaintext>> fpts;
+    Tensor<u64> out1, out0, ideal;
+    EXPECT(client.encryptImage(s0, meta, enc) == Code::OK && !enc.empty() && enc[0].size() == 2 &&
+               enc[0].coeff_modulus_size() == 2 && enc[0].poly_modulus_degree() == 4096,
+           "encryptImage: first-level ciphertexts in SEAL's layout");
+    EXPECT(server.encodeImage(s1, meta, share_pts) == Code::OK && share_pts.size() == enc.size(), "encodeImage");
+    EXPECT(server.encodeFilters(filters, meta, fpts) == Code::OK && fpts.size() == 3, "encodeFilters");
+    EXPECT(server.conv2DSS(enc, share_pts, fpts, meta, out_ct, out1) == Code::OK && out_ct[0].coeff_modulus_size() == 1,
+           "conv2DSS: last-level ciphertexts + share tensor");
+    EXPECT(client.decryptToTensor(out_ct, meta, out0) == Code::OK, "decryptToTensor");
+    EXPECT(server.idealFunctionality(x, filters, meta, ideal) == Code::OK && ideal.shape().IsSameSize(out0.shape()),
+           "idealFunctionality");
+    bool close = out0.shape().IsSameSize(out1.shape());
+    for (int64_t i = 0; close && i < ideal.NumElements(); ++i) {
+      const int64_t d = to_signed(out0.data()[i] + out1.data()[i] - ideal.data()[i], l);
+      close = d >= -1 && d <= 1;
+    }
+    EXPECT(close, "HomConv2DSS shares reconstruct to idealFunctionality within one unit (approximate re-sharing)");
+    // error behaviour of the reference
+    EXPECT(server.decryptToTensor(out_ct, meta, out0) == Code::ERR_CONFIG, "decryptToTensor without sk: ERR_CONFIG");
+    EXPECT(client.conv2DSS(enc, share_pts, fpts, meta, out_ct, out1) == Code::ERR_CONFIG, "conv2DSS without pk: ERR_CONFIG");
+    EXPECT(client.encryptImage(Tensor<u64>(TensorShape({5, 13, 12})), meta, enc) == Code::ERR_DIM_MISMATCH,
+           "encryptImage shape mismatch: ERR_DIM_MISMATCH");
+    std::vector<Tensor<u64>> two(filters.begin(), filters.begin() + 2);
+    EXPECT(server.encodeFilters(two, meta, fpts) == Code::ERR_INVALID_ARG, "encodeFilters count mismatch: ERR_INVALID_ARG");
+    EXPECT(server.encodeFilters(filters, meta, fpts) == Code::OK, "encodeFilters again");
+    std::vector<mm::he::Plaintext> fewer(share_pts.begin(), share_pts.end() - 1);
+    EXPECT(server.conv2DSS(enc, fewer, fpts, meta, out_ct, out1) == Code::ERR_DIM_MISMATCH,
+           "conv2DSS share count mismatch: ERR_DIM_MISMATCH");
+    for (auto &pt : fpts[1]) std::fill(pt.coeffs.begin(), pt.coeffs.end(), 0);
+    EXPECT(server.conv2DSS(enc, share_pts, fpts, meta, out_ct, out1) == Code::ERR_INTERNAL,
+           "conv2DSS with an all-zero filter: ERR_INTERNAL (conv2DOneFilter :573-580)");
   }
 
   // ---- HomConv and HomFC over a 2^37 ring (shipped ell=37, scripts/common.sh:48-56) ----------------
