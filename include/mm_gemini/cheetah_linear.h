@@ -10,19 +10,13 @@
 
 #include "mm_gemini/core.h"
 #include "mm_gemini/hom_conv2d_ss.h"
+#include "mm_gemini/hom_fc_ss.h"
 #include "mm_gemini/io.h"
 
 struct mmh_ctx;
 
 namespace gemini {
 
-struct HomFCSS {
-  struct Meta {  // hom_fc_ss.h:34-38
-    TensorShape input_shape;
-    TensorShape weight_shape;
-    bool is_shared_input;
-  };
-};
 struct HomBNSS {
   struct Meta {  // hom_bn_ss.h:33-38
     TensorShape ishape;

@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "host_util.h"
 #include "mm_hip.h"
 
 namespace mm {
@@ -28,41 +29,6 @@ Context::~Context() { mmh_ctx_destroy(ctx_); }
 
 namespace gemini {
 namespace {
-#define MM_TRY(expr)                                  \
-  do {                                                \
-    const int rc_ = (expr);                           \
-    if (rc_ != MMH_OK) return static_cast<Code>(rc_); \
-  } while (0)
-#define MM_ENSURE(cond, code) \
-  do {                        \
-    if (!(cond)) return code; \
-  } while (0)
-
-// device buffer of 64-bit words for the span of one call
-struct Dev {
-  uint64_t *p = nullptr;
-  int rc = MMH_OK;
-  explicit Dev(size_t words) {
-    void *q = nullptr;
-    rc = mmh_malloc(&q, (words ? words : 1) * 8);
-    p = static_cast<uint64_t *>(q);
-  }
-  ~Dev() { mmh_free(p); }
-  Dev(const Dev &) = delete;
-  int up(const uint64_t *src, size_t words, size_t at = 0) const {
-    return words ? mmh_memcpy_h2d(p + at, src, words * 8, nullptr) : MMH_OK;
-  }
-  int down(uint64_t *dst, size_t words, size_t at = 0) const {
-    const int r = words ? mmh_memcpy_d2h(dst, p + at, words * 8, nullptr) : MMH_OK;
-    return r ? r : mmh_stream_sync(nullptr);
-  }
-};
-bool seed_from_os(uint32_t key[8]) {
-  FILE *f = std::fopen("/dev/urandom", "rb");
-  const bool ok = f && std::fread(key, 1, 32, f) == 32;
-  if (f) std::fclose(f);
-  return ok;
-}
 mmh_conv_meta to_abi(const HomConv2DSS::Meta &meta) {
   return mmh_conv_meta{meta.ishape.channels(), meta.ishape.height(),  meta.ishape.width(),
                        meta.fshape.height(),   meta.fshape.width(),   (int64_t)meta.n_filters,

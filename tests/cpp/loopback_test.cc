@@ -305,6 +305,57 @@ int main(int argc, char **argv) {
            "conv2DSS with an all-zero filter: ERR_INTERNAL (conv2DOneFilter :573-580)");
   }
 
+  // ---- gemini::HomFCSS class surface (hom_fc_ss.h:27-83), driven the way cheetah-api.cpp:447-520 does ----
+  {
+    const int l = 37;
+    const u64 t37 = 1ULL << l, m37 = t37 - 1;
+    mm::he::Context hctx(4096, {60, 49}, t37);
+    mm::he::SecretKey sk;
+    auto pk = std::make_shared<mm::he::PublicKey>();
+    mm::he::GenerateKeys(hctx, sk, *pk);
+    gemini::HomFCSS client, server;
+    EXPECT(client.setUp(hctx, sk) == Code::OK && server.setUp(hctx, std::nullopt, pk) == Code::OK, "HomFCSS::setUp");
+    gemini::HomFCSS::Meta meta{TensorShape({300}), TensorShape({70, 300}), true};
+    Tensor<u64> v(meta.input_shape), v0(meta.input_shape), v1(meta.input_shape), w(meta.weight_shape);
+    for (int i = 0; i < 300; ++i) {
+      v.data()[i] = (u64)((int64_t)(rng() % (1 << 13)) - (1 << 12)) & m37;
+      v0.data()[i] = rng() & m37, v1.data()[i] = (v.data()[i] - v0.data()[i]) & m37;
+    }
+    for (int i = 0; i < 70 * 300; ++i) w.data()[i] = (u64)((int64_t)(rng() % (1 << 13)) - (1 << 12)) & m37;
+    std::vector<mm::he::Ciphertext> enc, out_ct;
+    std::vector<mm::he::Plaintext> share_pts;
+    std::vector<std::vector<mm::he::Plaintext>> wpts;
+    Tensor<u64> out1, out0, ideal;
+    EXPECT(client.encryptInputVector(v0, meta, enc) == Code::OK && !enc.empty(), "encryptInputVector");
+    EXPECT(server.encodeInputVector(v1, meta, share_pts) == Code::OK && share_pts.size() == enc.size(), "encodeInputVector");
+    EXPECT(server.encodeWeightMatrix(w, meta, wpts) == Code::OK && !wpts.empty() && wpts[0].size() == enc.size(),
+           "encodeWeightMatrix");
+    EXPECT(server.matVecMul(wpts, enc, share_pts, meta, out_ct, out1) == Code::OK && out1.length() == 70, "matVecMul");
+    EXPECT(client.decryptToVector(out_ct, meta, out0) == Code::OK && out0.length() == 70, "decryptToVector");
+    EXPECT(server.idealFunctionality(w, v, meta, ideal) == Code::OK, "idealFunctionality");
+    bool close = true;
+    for (int i = 0; i < 70; ++i) {
+      const int64_t d = to_signed(out0.data()[i] + out1.data()[i] - ideal.data()[i], l);
+      close = close && d >= -1 && d <= 1;
+    }
+    EXPECT(close, "HomFCSS shares reconstruct to W * v within one unit (approximate re-sharing)");
+    EXPECT(server.decryptToVector(out_ct, meta, out0) == Code::ERR_CONFIG, "decryptToVector without sk: ERR_CONFIG");
+    EXPECT(client.encryptInputVector(Tensor<u64>(TensorShape({299})), meta, enc) == Code::ERR_DIM_MISMATCH,
+           "encryptInputVector shape mismatch: ERR_DIM_MISMATCH");
+    EXPECT(client.encryptInputVector(v0, meta, enc) == Code::OK, "encryptInputVector again");
+    std::vector<mm::he::Plaintext> fewer(share_pts.begin(), share_pts.end() - 1);
+    if (!fewer.empty() || share_pts.size() == 1)
+      EXPECT(server.matVecMul(wpts, enc, fewer, meta, out_ct, out1) == Code::ERR_DIM_MISMATCH,
+             "matVecMul share count mismatch: ERR_DIM_MISMATCH");
+    auto zeroed = wpts;
+    std::fill(zeroed[0][0].coeffs.begin(), zeroed[0][0].coeffs.end(), 0);
+    EXPECT(server.matVecMul(zeroed, enc, share_pts, meta, out_ct, out1) == Code::ERR_INVALID_ARG,
+           "matVecMul with an all-zero sub-matrix: ERR_INVALID_ARG (hom_fc_ss.cc:414-421)");
+    zeroed.pop_back();
+    EXPECT(zeroed.empty() || server.matVecMul(zeroed, enc, share_pts, meta, out_ct, out1) == Code::ERR_INVALID_ARG,
+           "matVecMul row-block count mismatch: ERR_INVALID_ARG");
+  }
+
   // ---- HomConv and HomFC over a 2^37 ring (shipped ell=37, scripts/common.sh:48-56) ----------------
   {
     const int l = 37;
