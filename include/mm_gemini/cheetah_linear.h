@@ -10,6 +10,7 @@
 
 #include "mm_gemini/core.h"
 #include "mm_gemini/hom_conv2d_ss.h"
+#include "mm_gemini/hom_bn_ss.h"
 #include "mm_gemini/hom_fc_ss.h"
 #include "mm_gemini/io.h"
 
@@ -17,14 +18,6 @@ struct mmh_ctx;
 
 namespace gemini {
 
-struct HomBNSS {
-  struct Meta {  // hom_bn_ss.h:33-38
-    TensorShape ishape;
-    TensorShape vec_shape;
-    uint64_t target_base_mod;
-    bool is_shared_input;
-  };
-};
 
 class CheetahLinear {
  public:

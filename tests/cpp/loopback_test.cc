@@ -356,6 +356,80 @@ int main(int argc, char **argv) {
            "matVecMul row-block count mismatch: ERR_INVALID_ARG");
   }
 
+  // ---- gemini::HomBNSS class surface (hom_bn_ss.h:25-112): SIMD path over p, direct path over 2^37 ----
+  {
+    const u64 p32 = 4293918721ULL;
+    mm::he::Context fctx(4096, {60, 49}, p32), rctx(4096, {60, 49}, 1ULL << 37);
+    mm::he::SecretKey fsk, rsk;
+    auto fpk = std::make_shared<mm::he::PublicKey>(), rpk = std::make_shared<mm::he::PublicKey>();
+    mm::he::GenerateKeys(fctx, fsk, *fpk);
+    mm::he::GenerateKeys(rctx, rsk, *rpk);
+    gemini::HomBNSS client, server;
+    EXPECT(client.setUp_Field(p32, fctx, fsk) == Code::OK && server.setUp_Field(p32, fctx, std::nullopt, fpk) == Code::OK,
+           "HomBNSS::setUp_Field");
+    EXPECT(client.setUp_Base(1ULL << 37, rctx, rsk) == Code::OK && server.setUp_Base(1ULL << 37, rctx, std::nullopt, rpk) == Code::OK,
+           "HomBNSS::setUp_Base");
+    gemini::HomBNSS wrong;
+    EXPECT(wrong.setUp_Field(65537, fctx) == Code::ERR_INVALID_ARG, "setUp_Field with another modulus: ERR_INVALID_ARG");
+    EXPECT(wrong.setUp_Field(1ULL << 37, rctx) == Code::ERR_INVALID_ARG, "setUp_Field without batching: ERR_INVALID_ARG");
+    const int nv = 5000;
+    gemini::HomBNSS::Meta vm{TensorShape({1, 1, 1}), TensorShape({nv}), p32, true};
+    Tensor<u64> xa(vm.vec_shape), xb(vm.vec_shape), ya(vm.vec_shape), yb(vm.vec_shape), sc(vm.vec_shape);
+    for (int i = 0; i < nv; ++i) {
+      xa.data()[i] = rng() % p32, xb.data()[i] = rng() % p32, ya.data()[i] = rng() % p32, yb.data()[i] = rng() % p32;
+      sc.data()[i] = rng() % p32;
+    }
+    auto mulp = [&](u64 a, u64 b) { return (u64)((unsigned __int128)a * b % p32); };
+    std::vector<mm::he::Ciphertext> ex, ey, oc;
+    std::vector<mm::he::Plaintext> px, py, ps;
+    Tensor<u64> o1, o0;
+    EXPECT(client.encryptVector(xb, vm, ex) == Code::OK && ex.size() == 2, "encryptVector: ceil(n / N) ciphertexts");
+    EXPECT(server.encodeVector(xa, vm, px) == Code::OK && server.encodeScales(sc, vm, ps) == Code::OK, "encodeVector / encodeScales");
+    EXPECT(server.bn(ex, px, ps, vm, oc, o1) == Code::OK && client.decryptToVector(oc, vm, o0) == Code::OK, "bn + decryptToVector");
+    bool ok = true;
+    for (int i = 0; i < nv; ++i) ok = ok && (o0.data()[i] + o1.data()[i]) % p32 == mulp((xa.data()[i] + xb.data()[i]) % p32, sc.data()[i]);
+    EXPECT(ok, "HomBNSS::bn shares reconstruct to (x_A + x_B) * scale mod p exactly");
+    EXPECT(client.encryptVector(yb, vm, ey) == Code::OK && server.encodeVector(ya, vm, py) == Code::OK, "second operand");
+    EXPECT(server.bole(ex, ey, px, py, vm, oc, o1) == Code::OK && client.decryptToVector(oc, vm, o0) == Code::OK, "bole + decryptToVector");
+    ok = true;
+    for (int i = 0; i < nv; ++i)
+      ok = ok && (o0.data()[i] + o1.data()[i]) % p32 == (mulp(xb.data()[i], ya.data()[i]) + mulp(yb.data()[i], xa.data()[i])) % p32;
+    EXPECT(ok, "HomBNSS::bole shares reconstruct to x_B * y_A + y_B * x_A mod p exactly (hom_bn_ss.cc:302-309)");
+    gemini::HomBNSS::Meta badm = vm;
+    badm.target_base_mod = 65537;
+    EXPECT(client.encryptVector(xb, badm, ex) == Code::ERR_OUT_BOUND, "encryptVector with another modulus: ERR_OUT_BOUND");
+    EXPECT(client.encryptVector(xb, vm, ex) == Code::OK, "encryptVector again");
+    std::vector<mm::he::Plaintext> one(ps.begin(), ps.begin() + 1);
+    EXPECT(server.bn(ex, px, one, vm, oc, o1) == Code::ERR_INVALID_ARG, "bn scale count mismatch: ERR_INVALID_ARG");
+    EXPECT(server.decryptToVector(oc, vm, o0) == Code::ERR_CONFIG, "decryptToVector without sk: ERR_CONFIG");
+    // direct path: channel-wise scaling of a C x H x W tensor mod 2^37
+    const u64 m37 = (1ULL << 37) - 1;
+    // (width 64: with a tile ragged in w the reference's own identity does not hold, tests/test_fc_bn_gpu.py)
+    gemini::HomBNSS::Meta tm{TensorShape({3, 70, 64}), TensorShape({3}), 1ULL << 37, true};
+    Tensor<u64> ta(tm.ishape), tb(tm.ishape), scales(TensorShape({3})), r0, r1;
+    for (int i = 0; i < 3 * 70 * 64; ++i) ta.data()[i] = rng() & m37, tb.data()[i] = rng() & m37;
+    for (int c = 0; c < 3; ++c) scales.data()[c] = (u64)((int64_t)(rng() % (1 << 13)) - (1 << 12)) & m37;
+    std::vector<mm::he::Ciphertext> et, ot;
+    std::vector<mm::he::Plaintext> pt;
+    EXPECT(client.encryptTensor(tb, tm, et) == Code::OK && server.encodeTensor(ta, tm, pt) == Code::OK && et.size() == pt.size(),
+           "encryptTensor / encodeTensor");
+    EXPECT(server.bn_direct(et, pt, scales, tm, ot, r1) == Code::OK && client.decryptToTensor(ot, tm, r0) == Code::OK,
+           "bn_direct + decryptToTensor");
+    ok = r0.shape().IsSameSize(tm.ishape) && r1.shape().IsSameSize(tm.ishape);
+    for (int c = 0; ok && c < 3; ++c)
+      for (int i = 0; i < 70 * 64; ++i) {
+        const int k = c * 4480 + i;
+        ok = ok && ((r0.data()[k] + r1.data()[k]) & m37) == (((ta.data()[k] + tb.data()[k]) * scales.data()[c]) & m37);
+      }
+    EXPECT(ok, "HomBNSS::bn_direct shares reconstruct to (x_A + x_B) * scale[c] mod 2^37 exactly");
+    EXPECT(server.bn_direct(et, pt, Tensor<u64>(TensorShape({4})), tm, ot, r1) == Code::ERR_CONFIG,
+           "bn_direct scale length mismatch: ERR_CONFIG");
+    et.pop_back();
+    EXPECT(server.bn_direct(et, pt, scales, tm, ot, r1) == Code::ERR_DIM_MISMATCH, "bn_direct ciphertext count mismatch: ERR_DIM_MISMATCH");
+    EXPECT(client.encryptTensor(Tensor<u64>(TensorShape({3, 70, 63})), tm, et) == Code::ERR_CONFIG,
+           "encryptTensor shape mismatch: ERR_CONFIG (hom_bn_ss.cc:527)");
+  }
+
   // ---- HomConv and HomFC over a 2^37 ring (shipped ell=37, scripts/common.sh:48-56) ----------------
   {
     const int l = 37;
