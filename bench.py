@@ -148,6 +148,25 @@ def conversion_leg(torch, openmm_amd):
         e1.record()
         torch.cuda.synchronize()
         res[f"cot_{key}_1e7_send_recv_us"] = e0.elapsed_time(e1) / 10 * 1e3
+    # ALICE's whole ring_to_field with the COT post-processing on the device: pre -> cot_send (mod p) -> post,
+    # operands resident (what is left on the host is Ferret's output and the 4 B per element of wire)
+    nb = C.c_size_t()
+    L.check(lib.mmh_cot_wire_bytes(n, l, p, 1, C.byref(nb)))
+    wire = torch.empty((nb.value + 7) // 8, dtype=torch.int64, device="cuda")
+    y0 = torch.empty_like(x)
+
+    def chain():
+        L.check(lib.mmh_r2f_pre(1, L.dptr(x), n, l, p, L.dptr(tmp), L.dptr(msb), L.dptr(corr), s))
+        L.check(lib.mmh_cot_send(L.dptr(rcm), delta, seed, 0, L.dptr(corr), n, l, p, 1, L.dptr(y0), L.dptr(wire), s))
+        L.check(lib.mmh_r2f_post(1, L.dptr(tmp), L.dptr(msb), L.dptr(y0), n, l, p, L.dptr(out), s))
+    chain()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        chain()
+    e1.record()
+    torch.cuda.synchronize()
+    res["ring_to_field_1e7_sender_with_device_cot_us"] = e0.elapsed_time(e1) / 10 * 1e3
     # three AES-128 encryptions + two key schedules per element pair of launches
     res["cot_aes_blocks_per_s"] = 3.0 * n / (res["cot_prime_1e7_send_recv_us"] * 1e-6)
     return res
