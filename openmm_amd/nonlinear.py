@@ -40,7 +40,10 @@ class AuxProtocols:
         s = L._stream_ptr()
         corr = self._empty(size)
         L.check(self.lib.mmh_mux_pre(L.dptr(sel), L.dptr(x), size, bw_y, L.dptr(corr), s))
-        c, b = L.to_host(corr), sel.cpu().numpy()
+        if getattr(self.cot, "on_device", False) and getattr(self.cot_rev, "on_device", False):
+            c, b = corr, sel          # silent_ot.SilentOT takes device tensors: nothing crosses PCIe but the wire
+        else:
+            c, b = L.to_host(corr), sel.cpu().numpy()
         if self.party == ALICE:   # :79-81
             data_s = self.cot.send_cot(c, size, bw_y)
             data_r = self.cot_rev.recv_cot(b, size, bw_y)
@@ -63,9 +66,10 @@ class AuxProtocols:
         if party == ALICE:
             corr = self._empty(dim)
             L.check(self.lib.mmh_b2a_pre(L.dptr(x), dim, bw, L.dptr(corr), s))
-            y = self.cot.send_cot(L.to_host(corr), dim, bw)
+            y = self.cot.send_cot(corr if getattr(self.cot, "on_device", False) else L.to_host(corr), dim, bw)
         else:
-            y = self.cot.recv_cot(np.asarray(bits, dtype=np.uint8), dim, bw)
+            y = self.cot.recv_cot(x if getattr(self.cot, "on_device", False) else np.asarray(bits, dtype=np.uint8),
+                                  dim, bw)
         d_y = self._dev(y)
         L.check(self.lib.mmh_b2a_post(party, L.dptr(x), L.dptr(d_y), dim, bw, L.dptr(out), s))
         return L.to_host(out)
