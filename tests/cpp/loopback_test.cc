@@ -12,6 +12,7 @@
 
 #include "mm_gemini/cheetah_linear.h"
 #include "mm_gemini/library.h"
+#include "mm_gemini/nonlinear.h"
 #include "mm_gemini/silent_ot.h"
 #include "mm_gemini/truncation.h"
 
@@ -243,6 +244,49 @@ int main(int argc, char **argv) {
     EXPECT(otA.gid == 3 * g && otB.gid == 3 * g, "hash key counter advances by 8*ceil(n/8) per call on both sides");
     const u64 expect_bytes = 3 * 16 + (u64)n * 4 + (u64)(n / 8) * 8 * 4 + (u64)(n / 8) * 8 * 4;
     EXPECT(n % 8 != 0 || cio.first->counter == expect_bytes, "wire bytes: seed + 4 B (mod p), 32 b and 32 b per element");
+  }
+
+  // ---- ReLU, multiplexer and B2A of the USE_CHEETAH build (relu-ring.h:216-313, aux-protocols.cpp:62-126) over two
+  // COTs: once over the ideal COT, once over mm::SilentOT (device post-processing); the comparison stays ideal ----
+  for (int variant = 0; variant < 2; ++variant) {
+    auto cbox1 = std::make_shared<mm::IdealCOT::Mailbox>(), cbox2 = std::make_shared<mm::IdealCOT::Mailbox>();
+    mm::IdealCOT i1a(cbox1, 31), i1b(cbox1, 32), i2a(cbox2, 33), i2b(cbox2, 34);
+    auto fb1 = std::make_shared<mm::IdealFerret::Mailbox>(), fb2 = std::make_shared<mm::IdealFerret::Mailbox>();
+    mm::IdealFerret f1a(fb1, 41), f1b(fb1, 42), f2a(fb2, 43), f2b(fb2, 44);
+    auto io1 = mm::LoopbackIO::MakePair(), io2 = mm::LoopbackIO::MakePair();
+    // straight: ALICE sends; reversed: BOB sends
+    mm::SilentOT s1a(&f1a, io1.first.get(), 51), s1b(&f1b, io1.second.get(), 52);
+    mm::SilentOT s2b(&f2b, io2.second.get(), 53), s2a(&f2a, io2.first.get(), 54);
+    mm::COT *straight[2] = {variant ? (mm::COT *)&s1a : &i1a, variant ? (mm::COT *)&s1b : &i1b};
+    mm::COT *reversed[2] = {variant ? (mm::COT *)&s2a : &i2a, variant ? (mm::COT *)&s2b : &i2b};
+    auto abox = std::make_shared<mm::IdealAux::Mailbox>();
+    mm::IdealAux idealA(1, abox, 88), idealB(2, abox, 88);
+    mm::CotAuxProtocols auxA(1, straight[0], reversed[0], &idealA), auxB(2, straight[1], reversed[1], &idealB);
+    mm::ReLURingProtocol reluA(1, bw, &auxA), reluB(2, bw, &auxB);
+    std::vector<int64_t> v(n);
+    std::vector<u64> s[2], r[2], a2[2];
+    std::vector<uint8_t> dr[2], bits[2];
+    for (int q = 0; q < 2; ++q) s[q].resize(n), r[q].resize(n), a2[q].resize(n), dr[q].resize(n), bits[q].resize(n);
+    for (int i = 0; i < n; ++i) {
+      v[i] = (int64_t)(rng() % (1ULL << (bw - 2))) - (1LL << (bw - 3));
+      s[0][i] = rng() & mask, s[1][i] = ((u64)v[i] - s[0][i]) & mask;
+      bits[0][i] = rng() & 1, bits[1][i] = rng() & 1;
+    }
+    both(A, B, [&](Party &p) {
+      const int q = p.id - 1;
+      (q ? reluB : reluA).relu(r[q].data(), s[q].data(), n, dr[q].data());
+      (q ? auxB : auxA).B2A(bits[q].data(), a2[q].data(), n, 12);
+    });
+    bool relu_ok = true, msb_ok = true, b2a_ok = true;
+    for (int i = 0; i < n; ++i) {
+      relu_ok &= to_signed(r[0][i] + r[1][i], bw) == (v[i] > 0 ? v[i] : 0);
+      msb_ok &= (dr[0][i] ^ dr[1][i]) == (v[i] < 0 ? 1 : 0);
+      b2a_ok &= ((a2[0][i] + a2[1][i]) & 0xFFF) == (u64)(bits[0][i] ^ bits[1][i]);
+    }
+    EXPECT(relu_ok, variant ? "ReLU over SilentOT (device COT post-processing): shares of max(x, 0), exact"
+                            : "ReLU over the ideal COT: shares of max(x, 0), exact");
+    EXPECT(msb_ok, "drelu_res holds shares of msb(x) (relu-ring.h:244-252)");
+    EXPECT(b2a_ok, "B2A: boolean shares -> arithmetic shares mod 2^12");
   }
 
   // ---- gemini::HomConv2DSS class surface (hom_conv2d_ss.h:27-84), driven the way cheetah-api.cpp:332-445 does ----
