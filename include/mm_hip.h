@@ -61,6 +61,10 @@ int mmh_free(void *d_ptr);
  * allocation once warm).  This returns the cached blocks of the current device to the driver after a
  * device synchronisation.  No counterpart in the reference (SEAL's MemoryPool plays that role there). */
 int mmh_scratch_release(void);
+/* Page-locked host memory for staging buffers: copies to and from it run at the link's rate (pageable memory goes
+ * through the driver's bounce buffers).  No counterpart in the reference, whose data never leaves the host. */
+int mmh_host_alloc(void **h_ptr, size_t bytes);
+int mmh_host_free(void *h_ptr);
 int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int mmh_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
 int mmh_memset(void *d_dst, int value, size_t bytes, void *stream);

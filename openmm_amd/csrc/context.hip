@@ -336,6 +336,16 @@ extern "C" int mmh_free(void *d_ptr) {
   MMH_HIP(hipFree(d_ptr));
   return MMH_OK;
 }
+extern "C" int mmh_host_alloc(void **h_ptr, size_t bytes) {
+  MMH_REQUIRE(h_ptr, MMH_ERR_NULL_POINTER);
+  if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+    MMH_FAIL(MMH_ERR_MEMORY, "hipHostMalloc failed");
+  return MMH_OK;
+}
+extern "C" int mmh_host_free(void *h_ptr) {
+  MMH_HIP(hipHostFree(h_ptr));
+  return MMH_OK;
+}
 extern "C" int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream) {
   MMH_REQUIRE((d_dst && src) || bytes == 0, MMH_ERR_NULL_POINTER);
   MMH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));

@@ -200,10 +200,24 @@ struct CheetahLinear::Impl {
   // ---- ciphertext transport: u32 count, then the raw coefficient words (cheetah-api.cpp:11-29) ----
   // host staging for ciphertext batches (up to 128 MiB per layer): one grow-only buffer per object, so the
   // pages are touched once and not on every call
-  mutable std::vector<uint64_t> staging;
+  // (page-locked: the copies run at the link's rate and the pages are never touched by the host first)
+  struct Pinned {
+    uint64_t *p = nullptr;
+    size_t words = 0;
+    ~Pinned() {
+      if (p) mmh_host_free(p);
+    }
+  };
+  mutable Pinned staging;
   uint64_t *stage(size_t words) const {
-    if (staging.size() < words) staging.resize(words);
-    return staging.data();
+    if (staging.words < words) {
+      if (staging.p) mmh_host_free(staging.p);
+      staging.p = nullptr, staging.words = 0;
+      void *q = nullptr;
+      must(mmh_host_alloc(&q, words * 8), "mmh_host_alloc");
+      staging.p = static_cast<uint64_t *>(q), staging.words = words;
+    }
+    return staging.p;
   }
   void send_cts(const Dev &d, size_t n_cts, size_t words_per_ct) const {
     const size_t words = n_cts * words_per_ct;

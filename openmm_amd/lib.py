@@ -33,6 +33,8 @@ SIGNATURES = {
                      C.POINTER(_u64), C.POINTER(_u64)],
     "mmh_malloc": [C.POINTER(_vp), _sz],
     "mmh_free": [_vp],
+    "mmh_host_alloc": [C.POINTER(_vp), _sz],
+    "mmh_host_free": [_vp],
     "mmh_scratch_release": [],
     "mmh_memcpy_h2d": [_vp, _vp, _sz, _vp],
     "mmh_memcpy_d2h": [_vp, _vp, _sz, _vp],
