@@ -112,3 +112,20 @@ def test_packed_words_follow_ot_utils():
 def test_gid_advance_covers_ragged_batches():
     o = load()
     assert [o.mmo_cot_gids(n) for n in (0, 1, 8, 9, 16, 1003)] == [0, 8, 8, 16, 16, 1008]
+
+
+def test_abi_wire_sizes_match_the_oracle_without_gpu():
+    """mmh_cot_wire_bytes / mmh_cot_gids are host arithmetic: same values as the oracle over widths, moduli, lengths"""
+    import ctypes as C
+    from openmm_amd import lib as L
+    o, lib = load(), L.load_library()
+    nb, g = C.c_size_t(), C.c_uint64()
+    for n in (0, 1, 7, 8, 9, 255, 1003, 10 ** 7):
+        assert lib.mmh_cot_gids(n, C.byref(g)) == 0 and g.value == o.mmo_cot_gids(n)
+        for l in (1, 2, 7, 8, 12, 32, 37, 41, 63, 64):
+            assert lib.mmh_cot_wire_bytes(n, l, 0, 0, C.byref(nb)) == 0
+            assert nb.value == o.mmo_cot_wire_bytes(n, l, 0, 0)
+        for p in (2, 3, 255, 256, 257, 65537, 4293918721, 1 << 37, (1 << 61) - 1, (1 << 64) - 59):
+            assert lib.mmh_cot_wire_bytes(n, 0, p, 1, C.byref(nb)) == 0
+            assert nb.value == o.mmo_cot_wire_bytes(n, 0, p, 1)
+    assert lib.mmh_cot_wire_bytes(8, 0, 0, 0, C.byref(nb)) == 7 and lib.mmh_cot_wire_bytes(8, 0, 1, 1, C.byref(nb)) == 7
