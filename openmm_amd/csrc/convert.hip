@@ -2,7 +2,8 @@
 // COT call of SCI's Truncation::{ring_to_field, field_to_ring, field_to_ring_with_truncate,
 // ring_to_ring, ring_to_ring128} (SCI/src/BuildingBlocks/truncation.cpp:319-695) and the BOLE
 // cross term (SCI/src/cheetah/cheetah-api.cpp:648-649).  Pure streaming kernels (HBM-bound,
-// ~25 B per element); the COT itself stays on the host.  party: 1 = ALICE (COT sender), 2 = BOB.
+// ~25 B per element); the COT between them is the caller's (host, or cot.hip's device post-processing).
+// party: 1 = ALICE (COT sender), 2 = BOB.
 #include "common.hpp"
 
 namespace mmh {

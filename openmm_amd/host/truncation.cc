@@ -1,5 +1,5 @@
 // mm::Truncation: the five conversion methods of SCI's Truncation over libmm_hip's pre/post
-// kernels, with the COT on the host (SCI/src/BuildingBlocks/truncation.cpp:319-695).
+// kernels, with the COT behind the mm::COT interface (SCI/src/BuildingBlocks/truncation.cpp:319-695).
 #include "mm_gemini/truncation.h"
 
 #include <algorithm>
