@@ -134,3 +134,28 @@ def test_conversions_and_relu_over_device_cot(mm):
     relu = {q: ReLURingProtocol(q, bw, AuxProtocols(q, straight[q], reverse[q], ideal)) for q in (ALICE, BOB)}
     (ya, _), (yb, _) = _two_party(lambda: relu[ALICE].relu(n, sa), lambda: relu[BOB].relu(n, sb))
     assert torch.equal((ya + yb) & ((1 << bw) - 1), torch.clamp(v, min=0))
+
+
+@pytest.mark.parametrize("l,p", [(37, 0), (0, PRIMES[32])])
+def test_cot_shards_are_independent(mm, l, p):
+    """Element ranges cut at multiples of 8 are independent units (how the path shards over GPUs): a shard run with
+    gid0 + offset and its slice of the inputs writes exactly its slice of data0 and of the wire"""
+    import torch
+    from openmm_amd.lib import check, dptr, load_library
+    o, lib = load(), load_library()
+    n, cut, gid0, prime = 20011, 8 * 1203, 1 << 35, 1 if p else 0
+    data0, _, _, corr, wire, (rcm, _, delta, S) = cot_pair(o, n, l, p, SEED + 17, gid0=gid0)
+    got_data0, got_wire = [], []
+    for a, b in ((0, cut), (cut, n)):
+        m = b - a
+        nb = C.c_size_t()
+        check(lib.mmh_cot_wire_bytes(m, l, p, prime, C.byref(nb)))
+        d_rcm, d_corr = dev(rcm[2 * a:2 * b].copy()), dev(corr[a:b].copy())
+        d_data0 = torch.empty(m, dtype=torch.int64, device="cuda")
+        d_wire = torch.zeros((nb.value + 7) // 8, dtype=torch.int64, device="cuda")
+        check(lib.mmh_cot_send(dptr(d_rcm), u2(delta), u2(S), (gid0 + a) & 0xFFFFFFFFFFFFFFFF, dptr(d_corr), m, l, p,
+                               prime, dptr(d_data0), dptr(d_wire), None))
+        got_data0.append(host(d_data0))
+        got_wire.append(d_wire.cpu().numpy().view(np.uint8)[:nb.value])
+    assert np.array_equal(np.concatenate(got_data0), data0)
+    assert np.array_equal(np.concatenate(got_wire), wire)
