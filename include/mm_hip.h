@@ -188,6 +188,15 @@ int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t n, const u
  * encode reduces inputs mod t first (ring_to_field outputs are only congruent). */
 int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts, void *stream);
 int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals, void *stream);
+/* mmh_batch_decode without any allocation.  No counterpart in the reference: it is for callers that cannot
+ * call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it).  The working
+ * copy of the plaintexts lives in a static device array of 2^20 words (8 MiB per GPU, held until the process
+ * ends) instead of the scratch cache, so n is limited to 2^20 / N plaintexts (256 at N = 4096;
+ * mmh_batch_decode_noalloc_max reports it) and larger n fail with MMH_ERR_OUT_BOUND.  The context's device must
+ * be current.  Calls on one GPU share the array: calls that overlap on one GPU race.  Same results as
+ * mmh_batch_decode. */
+int mmh_batch_decode_noalloc(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals, void *stream);
+int mmh_batch_decode_noalloc_max(const mmh_ctx *ctx, size_t *max_n);
 
 /* =====================================================================================
  * Randomness on the device.  The reference samples through SEAL's UniformRandomGenerator

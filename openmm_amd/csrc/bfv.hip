@@ -5,6 +5,8 @@
 #include "common.hpp"
 #include "bfv_device.hpp"
 
+#include <mutex>
+
 namespace mmh {
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
                  int mod_base, hipStream_t s);
@@ -743,5 +745,64 @@ extern "C" int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_
   MMH_HIP(hipMemcpyAsync(tmp.p, d_pts, n * ctx->N * 8, hipMemcpyDeviceToDevice, s));
   CHECK_RC(ntt_dispatch(ctx, false, tmp.as<u64>(), n, 1, (int)ctx->L, s));
   LAUNCH(slot_gather_kernel, n * ctx->N, s, tmp.as<u64>(), d_vals, n * ctx->N, ctx->logN, ctx->d_slot_map);
+  return MMH_OK;
+}
+
+// ------------------------------------------------------------------- allocation-free decode
+// mmh_batch_decode for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc).  The copy of the plaintexts that the forward transform works on lives in a file-scope device
+// array instead of the scratch cache: 2^20 words = 8 MiB per GPU (256 plaintexts at N = 4096, the 2^20-element
+// vector of tests/bole_test.cpp:568), held until the process ends.  Every GPU has its own copy of the array at
+// its own address; the address is looked up once per device, with that device current, and host code uses
+// that pointer only.  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
+// threads) race.  Nothing in the array has to start at zero: a call overwrites the words it reads.
+namespace mmh {
+constexpr size_t kDecodeScratchWords = size_t(1) << 20;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned long long scratch[kDecodeScratchWords];
+static u64 *g_decode_scratch[kMaxDevices];
+static std::mutex g_decode_scratch_mu;
+
+static int decode_scratch_ptr(int device, u64 **out) {
+  MMH_REQUIRE(device >= 0 && device < kMaxDevices, MMH_ERR_CONFIG);
+  std::lock_guard<std::mutex> lock(g_decode_scratch_mu);
+  if (!g_decode_scratch[device]) {
+    int current = -1;
+    MMH_HIP(hipGetDevice(&current));
+    MMH_REQUIRE(current == device, MMH_ERR_CONFIG);
+    u64 *ptr = nullptr;
+    MMH_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    MMH_REQUIRE(ptr != nullptr, MMH_ERR_INTERNAL);
+    g_decode_scratch[device] = ptr;
+  }
+  *out = g_decode_scratch[device];
+  return MMH_OK;
+}
+}  // namespace mmh
+
+extern "C" int mmh_batch_decode_noalloc_max(const mmh_ctx *ctx, size_t *max_n) {
+  MMH_REQUIRE(ctx && max_n, MMH_ERR_NULL_POINTER);
+  *max_n = kDecodeScratchWords / ctx->N;
+  return MMH_OK;
+}
+
+extern "C" int mmh_batch_decode_noalloc(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals,
+                                        void *stream) {
+  CHECK_RC(check_bfv(ctx, 0));
+  MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
+  if (n > kDecodeScratchWords / ctx->N)
+    MMH_FAIL(MMH_ERR_OUT_BOUND, "n = " + std::to_string(n) + " plaintexts exceed the static scratch of " +
+                                    std::to_string(kDecodeScratchWords / ctx->N) + " (2^20 words per GPU)");
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_vals && d_pts, MMH_ERR_NULL_POINTER);
+  int current = -1;
+  MMH_HIP(hipGetDevice(&current));
+  MMH_REQUIRE(current == ctx->device, MMH_ERR_CONFIG);  // the context's tables live on ctx->device
+  u64 *tmp = nullptr;
+  CHECK_RC(decode_scratch_ptr(current, &tmp));
+  hipStream_t s = (hipStream_t)stream;
+  MMH_HIP(hipMemcpyAsync(tmp, d_pts, n * ctx->N * 8, hipMemcpyDeviceToDevice, s));
+  CHECK_RC(ntt_dispatch(ctx, false, tmp, n, 1, (int)ctx->L, s));
+  LAUNCH(slot_gather_kernel, n * ctx->N, s, tmp, d_vals, n * ctx->N, ctx->logN, ctx->d_slot_map);
   return MMH_OK;
 }

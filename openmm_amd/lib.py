@@ -60,6 +60,8 @@ SIGNATURES = {
     "mmh_truncate_and_zero": [_vp, _vp, _sz, _vp, _sz, _vp],
     "mmh_batch_encode": [_vp, _vp, _sz, _vp, _vp],
     "mmh_batch_decode": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_batch_decode_noalloc": [_vp, _vp, _sz, _vp, _vp],
+    "mmh_batch_decode_noalloc_max": [_vp, C.POINTER(_sz)],
     "mmh_chacha20_words": [C.POINTER(C.c_uint32), _u64, _u64, _vp, _sz, _vp],
     "mmh_sample_ternary": [C.POINTER(C.c_uint32), _u64, _vp, _sz, _vp],
     "mmh_sample_noise": [C.POINTER(C.c_uint32), _u64, _vp, _sz, _vp],
