@@ -329,6 +329,10 @@ int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan 
 int mmh_fc_plan_destroy(mmh_fc_plan *plan);
 /* split = getSplit's (d0, d1) (hom_fc_ss.cc:25-50); n_in = ceil(cols/d1), n_out = ceil(rows/d0) */
 int mmh_fc_plan_info(const mmh_fc_plan *plan, int64_t split[2], size_t *n_in_cts, size_t *n_out_cts);
+/* getSplit alone (hom_fc_ss.cc:25-50), host only, no device needed: the block (d0, d1) the plan would use.  The
+ * search is pruned (per d0 only the smallest d1 reaching that row's minimum is examined); tests sweep it against the
+ * reference's exhaustive double loop. */
+int mmh_fc_split(int64_t rows, int64_t cols, size_t N, int64_t split[2]);
 /* HomFCSS::encodeInputVector (hom_fc_ss.cc:275-325): -> [n_in][N] */
 int mmh_fc_encode_input(const mmh_fc_plan *plan, const uint64_t *d_vec, uint64_t *d_pts, void *stream);
 /* HomFCSS::encodeWeightMatrix (hom_fc_ss.cc:327-392): -> [n_out][n_in][N] */

@@ -165,6 +165,15 @@ extern "C" int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, m
   return MMH_OK;
 }
 
+extern "C" int mmh_fc_split(int64_t rows, int64_t cols, size_t N, int64_t split[2]) {
+  MMH_REQUIRE(split, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(rows > 0 && cols > 0 && N > 0, MMH_ERR_INVALID_ARG);
+  long d0 = 0, d1 = 0;
+  fc_split((long)rows, (long)cols, (long)N, d0, d1);
+  split[0] = d0, split[1] = d1;
+  return MMH_OK;
+}
+
 extern "C" int mmh_fc_plan_info(const mmh_fc_plan *p, int64_t split[2], size_t *n_in_cts, size_t *n_out_cts) {
   MMH_REQUIRE(p, MMH_ERR_NULL_POINTER);
   if (split) split[0] = p->d0, split[1] = p->d1;

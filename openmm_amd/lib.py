@@ -93,6 +93,7 @@ SIGNATURES = {
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],
     "mmh_fc_plan_destroy": [_vp],
+    "mmh_fc_split": [C.c_int64, C.c_int64, _sz, C.POINTER(C.c_int64)],
     "mmh_fc_plan_info": [_vp, C.POINTER(C.c_int64), C.POINTER(_sz), C.POINTER(_sz)],
     "mmh_fc_encode_input": [_vp, _vp, _vp, _vp],
     "mmh_fc_encode_weights": [_vp, _vp, _vp, _vp],
@@ -183,7 +184,8 @@ def dptr(t):
     """Device pointer of a contiguous torch CUDA tensor (None -> NULL)."""
     if t is None:
         return _vp(0)
-    assert t.is_cuda and t.is_contiguous()
+    if not (t.is_cuda and t.is_contiguous()):   # a host or strided pointer would fault inside a kernel
+        raise MMHError(7, "dptr: expected a contiguous CUDA tensor")
     return _vp(t.data_ptr())
 
 

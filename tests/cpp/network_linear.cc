@@ -4,7 +4,8 @@
 // the shapes of networks/main_{sqnet,resnet50}.cpp, both parties call Conv2DWrapper on fresh additive
 // shares (NHWC) with synthetic weights; a sample of outputs is reconstructed and compared with the
 // cleartext convolution (|err| <= 1, library_fixed_uniform_cheetah.cpp:199).  Prints per-network totals.
-//   usage: network_linear [sqnet|resnet50] [samples per layer = 512]
+// ResNet50 also runs its FC 2048 -> 1001 through MatMul2D (networks/main_resnet50.cpp:6333), every output checked.
+//   usage: network_linear [sqnet|resnet50|densenet121] [samples per layer = 512]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,20 @@ static const Shape kResnet50[] = {
     {1024, 14, 14, 1, 1, 512, 0, 1, 1}, {512, 16, 16, 3, 3, 512, 0, 2, 1}, {512, 7, 7, 1, 1, 2048, 0, 1, 3},
     {2048, 7, 7, 1, 1, 512, 0, 1, 2}, {512, 7, 7, 3, 3, 512, 1, 1, 2}};
 
+// DenseNet121 (networks/main_densenet121.cpp): stem, four dense blocks of (1x1 C -> 128, 3x3 128 -> 32) pairs with C
+// growing by 32, three 1x1 transitions, the 1x1 classifier on the pooled 1x1 image: 121 convolutions
+static std::vector<Shape> densenet121() {
+  std::vector<Shape> v{{3, 224, 224, 7, 7, 64, 3, 2, 1}};
+  const int hw[4] = {56, 28, 14, 7}, c0[4] = {64, 128, 256, 512}, layers[4] = {6, 12, 24, 16}, trans[4] = {128, 256, 512, 0};
+  for (int b = 0; b < 4; ++b) {
+    for (int k = 0; k < layers[b]; ++k) v.push_back({c0[b] + 32 * k, hw[b], hw[b], 1, 1, 128, 0, 1, 1});
+    v.push_back({128, hw[b], hw[b], 3, 3, 32, 1, 1, layers[b]});
+    if (trans[b]) v.push_back({c0[b] + 32 * layers[b], hw[b], hw[b], 1, 1, trans[b], 0, 1, 1});
+  }
+  v.push_back({1024, 1, 1, 1, 1, 1000, 0, 1, 1});
+  return v;
+}
+
 static int64_t to_signed(u64 v, int bw) {
   v &= (1ULL << bw) - 1;
   return (v >> (bw - 1)) ? (int64_t)v - (int64_t)(1ULL << bw) : (int64_t)v;
@@ -43,9 +58,11 @@ static int64_t to_signed(u64 v, int bw) {
 
 int main(int argc, char **argv) {
   const bool resnet = argc > 1 && !std::strcmp(argv[1], "resnet50");
+  const bool densenet = argc > 1 && !std::strcmp(argv[1], "densenet121");
   const int samples = argc > 2 ? std::atoi(argv[2]) : 512;
-  const Shape *net = resnet ? kResnet50 : kSqnet;
-  const size_t n_shapes = resnet ? sizeof(kResnet50) / sizeof(Shape) : sizeof(kSqnet) / sizeof(Shape);
+  const std::vector<Shape> dense = densenet121();
+  const Shape *net = densenet ? dense.data() : (resnet ? kResnet50 : kSqnet);
+  const size_t n_shapes = densenet ? dense.size() : (resnet ? sizeof(kResnet50) / sizeof(Shape) : sizeof(kSqnet) / sizeof(Shape));
   const int l = 37;
   const u64 mask = (1ULL << l) - 1;
   std::mt19937_64 rng(0x4D264D);
@@ -117,9 +134,33 @@ int main(int argc, char **argv) {
                 sh.W, sh.fh, sh.fw, sh.M, sh.stride, sh.count, ms);
     total_ms += ms;
   }
+  if (resnet) {  // FC 2048 -> 1001 on the pooled features: MatMul2D(1, 2048, 1001, x, W, out, false)
+    const int in = 2048, outn = 1001;
+    std::vector<int64_t> x(in), w((size_t)in * outn);
+    std::vector<u64> xs[2] = {std::vector<u64>(in), std::vector<u64>(in)}, wu(w.size());
+    std::vector<u64> out[2] = {std::vector<u64>(in), std::vector<u64>(in)};  // row stride = input columns (:126-127)
+    for (int i = 0; i < in; ++i) {
+      x[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11);
+      xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
+    }
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11), wu[i] = (u64)w[i];
+    lib[0].kIsSharedInput = lib[1].kIsSharedInput = true;
+    const auto t0 = std::chrono::steady_clock::now();
+    both([&](int s) { MatMul2D(1, in, outn, xs[s].data(), wu.data(), out[s].data(), false); });
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    bool ok = true;
+    for (int m = 0; m < outn && ok; ++m) {
+      int64_t acc = 0;
+      for (int c = 0; c < in; ++c) acc += x[c] * w[(size_t)c * outn + m];
+      ok = std::llabs(to_signed(out[0][m] + out[1][m], l) - acc) <= 1;
+    }
+    if (!ok) ++failures;
+    std::printf("%s fc   2048 -> 1001 through MatMul2D: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", ms);
+    total_ms += ms;
+  }
   std::printf("%s: %d convolutions through Conv2DWrapper, both parties in-process, %.1f ms in total (host tensors in,\n"
               "host tensors out, encryption, transport through a byte pipe and decryption included)\n",
-              resnet ? "ResNet50" : "SqueezeNet", layers, total_ms);
+              densenet ? "DenseNet121" : (resnet ? "ResNet50" : "SqueezeNet"), layers, total_ms);
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL PASSED", failures);
   return failures ? 1 : 0;
 }

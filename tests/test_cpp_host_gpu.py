@@ -29,6 +29,22 @@ def test_squeezenet_linear_layers_through_the_layer_adapters():
     assert r.returncode == 0 and "ALL PASSED" in r.stdout and "26 convolutions" in r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("net,count", [("resnet50", 53), ("densenet121", 121)])
+def test_network_linear_layers_through_the_layer_adapters(net, count):
+    """BASELINE.json configs[4] in loop-back: every convolution of ResNet50 (53, plus the FC 2048 -> 1001 through
+    MatMul2D) and DenseNet121 (121) through Conv2DWrapper on NHWC shares, both parties in-process, sampled outputs
+    within 1 of the cleartext convolution (library_fixed_uniform_cheetah.cpp:199,:404)"""
+    exe = os.path.join(ROOT, "tests", "cpp", "network_linear")
+    assert os.path.exists(exe), "build it with __graft_entry__.build() (make -C tests/cpp)"
+    r = subprocess.run([exe, net, "96"], capture_output=True, text=True, timeout=280)
+    print(r.stdout[-6000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout and f"{count} convolutions" in r.stdout
+    assert "FAIL " not in r.stdout
+    if net == "resnet50":
+        assert "PASS fc   2048 -> 1001" in r.stdout
+
+
 def test_host_library_links_without_gpu():
     """CPU: libmm_gemini.so loads and resolves against libmm_hip.so"""
     import ctypes

@@ -98,7 +98,7 @@ def test_fc_rejects_zero_block(mm):
     assert ei.value.code == 7  # ERR_INVALID_ARG, hom_fc_ss.cc:419
 
 
-@pytest.mark.parametrize("n", [1, 100, 4096, 10000])
+@pytest.mark.parametrize("n", [1, 100, 4096, 10000, 1 << 20])   # 2^20: tests/bole_test.cpp:568, BASELINE configs[0,2]
 def test_bole_bn_bit_exact(mm, n):
     from openmm_amd.hom_bn_ss import HomBNSS, Meta
     from openmm_amd.truncation import bole_cross_term

@@ -79,3 +79,30 @@ def test_bn_direct_flow_reconstructs(ishape, shared):
     s = scales.view(np.int64).astype(object)[:, None, None]
     want = ((x0.astype(object) + x1.astype(object)) * s) % T
     assert np.array_equal((dec.astype(object) + share1.astype(object)) % T, want)
+
+
+def test_fc_split_pruned_search_equals_exhaustive_scan():
+    """mmh_fc_split (geometry.hpp fc_split: pruned search, what every FC plan uses) against the oracle's literal
+    restatement of getSplit's double loop (hom_fc_ss.cc:36-48) over a rows x cols grid at N = 4096 and 8192: small
+    shapes, shapes around N, primes, powers of two, the shipped networks' FC layers, first-minimum ties"""
+    import ctypes as C
+    from openmm_amd import lib as L
+    from tests.oracle_binding import load
+    from tests.oracle_layers import setup_geom
+    lib, orc = L.load_library(), load()
+    setup_geom(orc)
+    dims = sorted(set(list(range(1, 34)) + [47, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 500, 512, 1000, 1001,
+                                            1024, 2047, 2048, 2049, 4095, 4096, 4097, 5000, 8191, 8192, 8193, 9216,
+                                            10007, 25088]))
+    got, want = (C.c_int64 * 2)(), (C.c_long * 2)()
+    n = 0
+    for N in (4096, 8192):
+        for rows in dims:
+            for cols in dims:
+                if N == 8192 and (rows > 2100 and cols > 2100):
+                    continue          # the exhaustive scan is O(min(N,rows) * min(N,cols)); keep the sweep in seconds
+                assert lib.mmh_fc_split(rows, cols, N, got) == 0
+                orc.mmo_fc_split(rows, cols, N, want)
+                assert (got[0], got[1]) == (want[0], want[1]), (N, rows, cols)
+                n += 1
+    assert n > 5000
