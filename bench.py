@@ -264,7 +264,8 @@ def densenet121_convs():
     return convs
 
 
-def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None, prefix="resnet50", with_fc=True):
+def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None, prefix="resnet50", with_fc=True,
+                 all_modes=True):
     """Second half of BASELINE.json's metric: server-side HE compute of all 53 ResNet50 conv layers
     + FC 2048->1001 (what CheetahLinear::conv2d / ::fc run between receiving the client's
     ciphertexts and sending the result, cheetah-api.cpp:417-445, :520-548): filter encoding and
@@ -293,18 +294,14 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        w = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        return float(w.item())
+        return max_over_ranks((time.perf_counter() - t0) / reps * 1e3, torch, dist, world)
 
     srv = HomConv2DSS()
     srv.setUp(ctx, pk_ntt=pk)
-    per_layer, total, cached_total = [], 0.0, 0.0
+    per_layer, total, cached_total, d2h_total, repl_total = [], 0.0, 0.0, 0.0, 0.0
     for (c, h, w, fh, fw, m, same, stride, count) in (convs or RESNET50_CONVS):
         shared = c != 3  # first conv runs with kIsSharedInput=false (main_resnet50.cpp:4979)
         meta = Meta((c, h, w), (c, fh, fw), m, same, stride, shared)
-        sh = ShardedConv(srv, meta) if world > 1 else None
         plan = srv.plan(meta)
         cts = rnd(0, 1 << 62, plan.n_in, 2, 2, N) % qs.view(1, 1, 2, 1)
         share = rnd(0, t, c, h, w)
@@ -312,26 +309,48 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
         n_out = plan.n_out
         rand = (rnd(-1, 2, n_out, N), rnd(-8, 9, n_out, N), rnd(0, 1 << 62, n_out, N) % ctx.q[0])
 
-        def layer():
-            if sh is None:   # encodeImage + encodeFilters + conv2DSS in one device call
-                return srv.conv2DSSFromTensors(cts, share if shared else None, filters, meta, rand)
-            s = srv.encodeImage(share, meta) if shared else None
-            return sh.run(cts, s, filters, lambda k: tuple(r[:k] for r in rand))
+        def layer():   # encodeImage + encodeFilters + conv2DSS in one device call
+            return srv.conv2DSSFromTensors(cts, share if shared else None, filters, meta, rand)
 
-        ms = wall_ms(layer)
-        per_layer.append(round(ms, 3))
-        total += ms * count
-        if sh is None:   # static weights prepared once per model (not what the reference does: reported apart)
+        if world == 1:
+            ms = wall_ms(layer)
+            # static weights prepared once per model (not what the reference does: reported apart)
             prep = srv.prepareFilters(filters, meta)
             cached_total += count * wall_ms(lambda: srv.conv2DSSPrepared(
                 cts, srv.encodeImage(share, meta) if shared else None, prep, meta, rand))
             del prep
+        else:
+            # output filters sharded over the ranks, one-call form per rank, assembled on rank 0 by (a) one RCCL
+            # gather into a pre-sized device buffer, (b) per-rank async D2H into one shared page-locked host buffer
+            times = {}
+            for mode in (("gather", "d2h") if all_modes else ("gather",)):
+                sh = ShardedConv(srv, meta, mode=mode)
+                lo = sh.lo * plan.n_spatial
+                times[mode] = wall_ms(lambda: sh.run(cts, share if shared else None, filters,
+                                                     lambda k: tuple(r[lo:lo + k] for r in rand)))
+                del sh
+            ms = times["gather"]
+            if all_modes:
+                d2h_total += times["d2h"] * count
+                # (c) replicated: every rank runs whole layers of its own inference (no sharding, no exchange)
+                repl_total += wall_ms(layer) * count
+        per_layer.append(round(ms, 3))
+        total += ms * count
         del cts, share, filters, rand
+    multi = {}
+    if world > 1 and all_modes:
+        multi = {f"{prefix}_he_linear_d2h_ms": d2h_total,
+                 f"{prefix}_replicated_ms_per_inference": repl_total,
+                 f"{prefix}_replicated_inferences_per_s": world / (repl_total / 1e3),
+                 f"{prefix}_modes": "he_linear_ms: filters sharded, RCCL gather to rank 0 (device); d2h_ms: filters "
+                                    "sharded, per-rank async copy into one shared pinned host buffer; replicated: one "
+                                    "independent inference per rank (FC excluded)"}
     if not with_fc:
         out = {f"{prefix}_he_linear_ms": total, f"{prefix}_conv_layers": sum(x[-1] for x in convs),
                f"{prefix}_conv_ms_per_shape": per_layer}
         if world == 1:
             out[f"{prefix}_he_linear_prepared_filters_ms"] = cached_total
+        out.update(multi)
         return out
     fc = HomFCSS()
     fc.setUp(ctx, pk_ntt=pk)
@@ -343,10 +362,44 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
     fc_ms = wall_ms(lambda: fc.matVecMul(fc.encodeWeightMatrix(wmat, fmeta), vec_ct,
                                          fc.encodeInputVector(vec, fmeta), fmeta, frand))
     out = {"resnet50_he_linear_ms": total + fc_ms, "resnet50_conv_layers": 53, "resnet50_fc_ms": round(fc_ms, 3),
-           "resnet50_conv_ms_per_shape": per_layer, "resnet50_sharding": f"output filters x{world}, gather on rank 0"}
+           "resnet50_conv_ms_per_shape": per_layer, "resnet50_sharding": f"output filters x{world}, gather on rank 0" if world > 1 else "none"}
     if world == 1:
         out["resnet50_he_linear_prepared_filters_ms"] = cached_total + fc_ms
+    out.update(multi)
+    if "resnet50_he_linear_d2h_ms" in out:
+        out["resnet50_he_linear_d2h_ms"] += fc_ms
     return out
+
+
+def max_over_ranks(x, torch, dist, world):
+    if world == 1:
+        return x
+    dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    w = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    return float(w.item())
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, from this process,
+    which has not touched the GPU (no torch import yet); rank 0 prints the line.  Under torch.distributed.run the
+    ranks already exist (WORLD_SIZE is set) and this is not used."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def timed(fn, steps, warmup, torch, dist, world):
@@ -367,10 +420,7 @@ def timed(fn, steps, warmup, torch, dist, world):
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+    wall = max_over_ranks(wall, torch, dist, world)
     return wall, ev0.elapsed_time(ev1) / 1e3 / steps  # job wall seconds, per-launch device seconds
 
 
@@ -382,18 +432,33 @@ def main():
     ap.add_argument("--polys", type=int, default=16384, help="two-limb polynomials per GPU per step")
     ap.add_argument("--headline-only", action="store_true", help="only the timed NTT loop (for rocprofv3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo rehearses N ranks on fewer GPUs (rank r uses device r %% device_count)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python bench.py --gpus N starts them itself)")
 
     import torch
     import torch.distributed as dist
     import openmm_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local >= n_dev:
+        sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {n_dev} visible); --backend gloo rehearses")
+    local %= max(n_dev, 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     ctx = openmm_amd.Context(4096, (60, 49), 0, device=local)
     gen = torch.Generator(device="cuda").manual_seed(0x4D264D + rank)
@@ -427,9 +492,9 @@ def main():
     if not args.headline_only:
         net = resnet50_leg(torch, dist, openmm_amd, local, world, rank)
         sq = resnet50_leg(torch, dist, openmm_amd, local, world, rank, convs=SQUEEZENET_CONVS, prefix="squeezenet",
-                          with_fc=False)
+                          with_fc=False, all_modes=False)
         dn = resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=3, convs=densenet121_convs(),
-                          prefix="densenet121", with_fc=False)
+                          prefix="densenet121", with_fc=False, all_modes=False)
         dn.pop("densenet121_conv_ms_per_shape")
         if rank == 0:
             extra.update(net)

@@ -454,6 +454,7 @@ using namespace mmh;
 
 extern "C" int mmh_add_plain(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, const uint64_t *d_pts,
                              size_t n, int sub, uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_cts && d_pts && d_out, MMH_ERR_NULL_POINTER);
@@ -471,6 +472,7 @@ extern "C" int mmh_add_plain(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, 
 
 extern "C" int mmh_plain_lift_ntt(const mmh_ctx *ctx, int lv, const uint64_t *d_pts, size_t n,
                                   uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_pts && d_out, MMH_ERR_NULL_POINTER);
@@ -483,6 +485,7 @@ extern "C" int mmh_dyadic_mac(const mmh_ctx *ctx, int lv, const uint64_t *d_cts_
                               const uint64_t *d_pts_ntt, size_t n_pts, size_t n_o1, size_t n_o2, size_t K,
                               size_t ct_sk, size_t ct_s2, size_t pt_s1, size_t pt_sk, size_t pt_s2,
                               uint64_t *d_out_ntt, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n_o1 == 0 || n_o2 == 0) return MMH_OK;
   MMH_REQUIRE(d_cts_ntt && d_pts_ntt && d_out_ntt, MMH_ERR_NULL_POINTER);
@@ -504,6 +507,7 @@ extern "C" int mmh_mul_plain_acc(const mmh_ctx *ctx, int lv, const uint64_t *d_c
                                  const uint64_t *d_pts, size_t n_pts, size_t n_o1, size_t n_o2, size_t K,
                                  size_t ct_sk, size_t ct_s2, size_t pt_s1, size_t pt_sk, size_t pt_s2,
                                  uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n_o1 == 0 || n_o2 == 0) return MMH_OK;
   MMH_REQUIRE(d_cts && d_pts && d_out, MMH_ERR_NULL_POINTER);
@@ -523,6 +527,7 @@ extern "C" int mmh_mul_plain_acc(const mmh_ctx *ctx, int lv, const uint64_t *d_c
 
 extern "C" int mmh_ct_add(const mmh_ctx *ctx, int lv, uint64_t *d_a, const uint64_t *d_b, size_t n,
                           void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_a && d_b, MMH_ERR_NULL_POINTER);
@@ -534,6 +539,7 @@ extern "C" int mmh_ct_add(const mmh_ctx *ctx, int lv, uint64_t *d_a, const uint6
 
 extern "C" int mmh_mod_switch_to_last(const mmh_ctx *ctx, const uint64_t *d_in, size_t n, uint64_t *d_out,
                                       void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 0));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
@@ -550,6 +556,7 @@ extern "C" int mmh_mod_switch_to_last(const mmh_ctx *ctx, const uint64_t *d_in, 
 extern "C" int mmh_encrypt_zero_asym(const mmh_ctx *ctx, int lv, const uint64_t *d_pk_ntt, const int64_t *d_u,
                                      const int64_t *d_e0, const int64_t *d_e1, size_t n, uint64_t *d_out,
                                      void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_pk_ntt && d_u && d_out, MMH_ERR_NULL_POINTER);
@@ -570,6 +577,7 @@ extern "C" int mmh_encrypt_zero_asym(const mmh_ctx *ctx, int lv, const uint64_t 
 extern "C" int mmh_encrypt_symmetric(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt, const uint64_t *d_a,
                                      const int64_t *d_e, const uint64_t *d_pts, size_t n, uint64_t *d_out,
                                      void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_sk_ntt && d_a && d_e && d_out, MMH_ERR_NULL_POINTER);
@@ -589,6 +597,7 @@ extern "C" int mmh_encrypt_symmetric(const mmh_ctx *ctx, int lv, const uint64_t 
 
 extern "C" int mmh_make_public_key(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_a_ntt,
                                    const int64_t *d_e, uint64_t *d_pk_ntt, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 0));
   MMH_REQUIRE(d_sk_ntt && d_a_ntt && d_e && d_pk_ntt, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
@@ -605,6 +614,7 @@ extern "C" int mmh_make_public_key(const mmh_ctx *ctx, const uint64_t *d_sk_ntt,
 
 extern "C" int mmh_decrypt(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
                            size_t n, uint64_t *d_pts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_sk_ntt && d_cts && d_pts, MMH_ERR_NULL_POINTER);
@@ -625,6 +635,7 @@ extern "C" int mmh_decrypt(const mmh_ctx *ctx, int lv, const uint64_t *d_sk_ntt,
 extern "C" int mmh_scale_and_round(const mmh_ctx *ctx, int lv, const uint64_t *d_polys, size_t n,
                                    const uint32_t *d_targets, size_t n_targets, uint64_t *d_out,
                                    void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (!d_targets) n_targets = ctx->N;
   if (n == 0 || n_targets == 0) return MMH_OK;
@@ -637,6 +648,7 @@ extern "C" int mmh_scale_and_round(const mmh_ctx *ctx, int lv, const uint64_t *d
 
 extern "C" int mmh_sub_rns_poly(const mmh_ctx *ctx, int lv, uint64_t *d_cts, const uint64_t *d_r, size_t n,
                                 void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, lv));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_cts && d_r, MMH_ERR_NULL_POINTER);
@@ -647,6 +659,7 @@ extern "C" int mmh_sub_rns_poly(const mmh_ctx *ctx, int lv, uint64_t *d_cts, con
 }
 
 extern "C" int mmh_flood_add(const mmh_ctx *ctx, uint64_t *d_cts, const uint64_t *d_random, size_t n, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 0));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_cts && d_random, MMH_ERR_NULL_POINTER);
@@ -668,6 +681,7 @@ extern "C" int mmh_flood_add(const mmh_ctx *ctx, uint64_t *d_cts, const uint64_t
 
 extern "C" int mmh_reduce_mod_t(const mmh_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t count,
                                 void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 0));
   if (count == 0) return MMH_OK;
   MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
@@ -685,6 +699,7 @@ extern "C" int mmh_truncate_masks(const mmh_ctx *ctx, uint64_t *mask0, uint64_t 
 
 extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t n, const uint8_t *d_keep,
                                      size_t keep_period, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 1));
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(d_cts, MMH_ERR_NULL_POINTER);
@@ -724,6 +739,7 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
 
 extern "C" int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts,
                                 void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 0));
   MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
   if (n == 0) return MMH_OK;
@@ -735,6 +751,7 @@ extern "C" int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size
 
 extern "C" int mmh_batch_decode(const mmh_ctx *ctx, const uint64_t *d_pts, size_t n, uint64_t *d_vals,
                                 void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   CHECK_RC(check_bfv(ctx, 0));
   MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
   if (n == 0) return MMH_OK;

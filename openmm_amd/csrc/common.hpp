@@ -65,6 +65,7 @@ struct BfvConsts {
 };
 
 void set_error(const std::string &msg);
+int ctx_device(const mmh_ctx *ctx);
 // call-scoped device scratch from a cache of blocks reused in stream order (context.hip); same
 // calling convention as hipMallocAsync / hipFreeAsync
 hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t s);
@@ -86,6 +87,39 @@ hipError_t scratch_free(void *p, hipStream_t s);
   do {                                                                         \
     if (!(cond)) MMH_FAIL(code, "requirement failed: " #cond);                 \
   } while (0)
+
+// Every entry point that takes a context or a plan runs on that context's device: the guard makes it current for
+// the length of the call and puts the caller's device back afterwards (torch and other libraries in the process keep
+// their own notion of the current device).  hipGetDevice is a thread-local read; hipSetDevice is only issued when
+// the devices differ.  The stream argument must then belong to the context's device: the caller's business.
+struct DeviceScope {
+  int prev = -1, rc = MMH_OK;
+  bool switched = false;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;  // null context: the entry point reports it
+    if (hipGetDevice(&prev) != hipSuccess) {
+      rc = MMH_ERR_INTERNAL;
+      return;
+    }
+    if (prev != device) {
+      if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();  // do not leave the failure behind for the next launch check to find
+        rc = MMH_ERR_CONFIG;
+      } else {
+        switched = true;
+      }
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define MMH_DEVICE_SCOPE(ctxp)                                                              \
+  const mmh_ctx *dev_scope_ctx_ = (ctxp);                                                   \
+  ::mmh::DeviceScope dev_scope_(dev_scope_ctx_ ? ::mmh::ctx_device(dev_scope_ctx_) : -1);   \
+  if (dev_scope_.rc) MMH_FAIL(dev_scope_.rc, "cannot make the context's device current")
 
 // ---------------------------------------------------------------- device math
 __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
@@ -226,3 +260,6 @@ struct mmh_ctx {
   uint32_t *d_slot_map = nullptr;  // BatchEncoder index map (batching only)
   std::vector<void *> allocs;
 };
+namespace mmh {
+inline int ctx_device(const mmh_ctx *ctx) { return ctx->device; }
+}  // namespace mmh

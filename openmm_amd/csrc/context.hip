@@ -238,7 +238,8 @@ extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t
     MMH_REQUIRE(t == 0 || q[l] > t, MMH_ERR_INVALID_ARG);  // fast plain lift needs q_l > t
     for (size_t k = 0; k < l; ++k) MMH_REQUIRE(q[k] != q[l], MMH_ERR_INVALID_ARG);
   }
-  MMH_HIP(hipSetDevice(device));
+  DeviceScope scope(device);  // tables are uploaded to `device`; the caller's current device is put back on return
+  if (scope.rc) MMH_FAIL(scope.rc, "cannot make device " + std::to_string(device) + " current");
   mmh_ctx *ctx = new mmh_ctx();
   ctx->device = device;
   ctx->N = N;
@@ -298,7 +299,7 @@ extern "C" int mmh_ctx_create_bits(mmh_ctx **out, size_t N, const int *bits, siz
 
 extern "C" int mmh_ctx_destroy(mmh_ctx *ctx) {
   if (!ctx) return MMH_OK;
-  (void)hipSetDevice(ctx->device);
+  DeviceScope scope(ctx->device);
   for (void *p : ctx->allocs) (void)hipFree(p);
   delete ctx;
   return MMH_OK;

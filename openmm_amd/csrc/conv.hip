@@ -796,6 +796,7 @@ extern "C" int mmh_conv_plan_destroy(mmh_conv_plan *p) {
 }
 
 extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *meta, mmh_conv_plan **out) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && meta && out, MMH_ERR_NULL_POINTER);
   *out = nullptr;
   MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
@@ -966,6 +967,7 @@ extern "C" int mmh_conv_plan_info(const mmh_conv_plan *p, size_t *n_in_cts, size
 }
 
 extern "C" int mmh_conv_encode_image(const mmh_conv_plan *p, const uint64_t *d_img, uint64_t *d_pts, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_img && d_pts, MMH_ERR_NULL_POINTER);
   const mmh_ctx *ctx = p->ctx;
   const size_t total = p->n_in << ctx->logN;
@@ -978,6 +980,7 @@ extern "C" int mmh_conv_encode_image(const mmh_conv_plan *p, const uint64_t *d_i
 
 extern "C" int mmh_conv_encode_filters(const mmh_conv_plan *p, const uint64_t *d_filters, uint64_t *d_pts,
                                        void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_filters && d_pts, MMH_ERR_NULL_POINTER);
   const mmh_ctx *ctx = p->ctx;
   hipStream_t s = (hipStream_t)stream;
@@ -993,6 +996,7 @@ extern "C" int mmh_conv_encode_filters(const mmh_conv_plan *p, const uint64_t *d
 
 extern "C" int mmh_conv_check_filters(const mmh_conv_plan *p, const uint64_t *d_filters, uint32_t *d_flag,
                                       void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_filters && d_flag, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   MMH_HIP(hipMemsetAsync(d_flag, 0, 4, s));
@@ -1004,6 +1008,7 @@ extern "C" int mmh_conv_check_filters(const mmh_conv_plan *p, const uint64_t *d_
 
 extern "C" int mmh_conv_encrypt_image(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_img,
                                       const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_sk_ntt && d_img && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
@@ -1131,6 +1136,7 @@ extern "C" int mmh_conv_server(const mmh_conv_plan *p, const uint64_t *d_in_cts,
                                const uint64_t *d_filter_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                                const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                                uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(d_filter_pts, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, d_filter_pts, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask,
                           d_out_cts, d_out_share, stream);
@@ -1141,6 +1147,7 @@ extern "C" int mmh_conv_server_exact(const mmh_conv_plan *p, const uint64_t *d_i
                                      const uint64_t *d_flood, const int64_t *d_u, const int64_t *d_e0,
                                      const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                                      uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(d_filter_pts && d_flood && d_e0, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, d_filter_pts, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask,
                           d_out_cts, d_out_share, stream, d_flood, d_e0);
@@ -1151,6 +1158,7 @@ extern "C" int mmh_conv_server_weights(const mmh_conv_plan *p, const uint64_t *d
                                        const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
                                        const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
                                        void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(d_filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask,
                           d_out_cts, d_out_share, stream);
@@ -1160,6 +1168,7 @@ extern "C" int mmh_conv_server_tensors(const mmh_conv_plan *p, const uint64_t *d
                                        const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                                        const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                                        uint64_t *d_out_share, uint32_t *d_zero_filter, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_filters, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share, MMH_ERR_DIM_MISMATCH);
   return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
@@ -1177,6 +1186,7 @@ extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {
 
 extern "C" int mmh_conv_filters_prepare(const mmh_conv_plan *p, const uint64_t *d_filters, mmh_conv_filters **out,
                                         void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_filters && out, MMH_ERR_NULL_POINTER);
   *out = nullptr;
   const mmh_ctx *ctx = p->ctx;
@@ -1223,6 +1233,7 @@ extern "C" int mmh_conv_server_prepared(const mmh_conv_plan *p, const uint64_t *
                                         const uint64_t *d_pk_ntt_last, const int64_t *d_u, const int64_t *d_e1,
                                         const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
                                         void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                           d_out_share, stream, nullptr, nullptr, filters);
@@ -1230,6 +1241,7 @@ extern "C" int mmh_conv_server_prepared(const mmh_conv_plan *p, const uint64_t *
 
 extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
                                 uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
   const mmh_ctx *ctx = p->ctx;
   hipStream_t s = (hipStream_t)stream;

@@ -130,6 +130,7 @@ extern "C" int mmh_fc_plan_destroy(mmh_fc_plan *p) {
 }
 
 extern "C" int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan **out) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && meta && out, MMH_ERR_NULL_POINTER);
   *out = nullptr;
   MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
@@ -183,6 +184,7 @@ extern "C" int mmh_fc_plan_info(const mmh_fc_plan *p, int64_t split[2], size_t *
 }
 
 extern "C" int mmh_fc_encode_input(const mmh_fc_plan *p, const uint64_t *d_vec, uint64_t *d_pts, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_vec && d_pts, MMH_ERR_NULL_POINTER);
   KLAUNCH(fc_encode_input_kernel, p->n_in << p->ctx->logN, stream, d_vec, d_pts, p->n_in, (long)p->meta.cols, p->d1,
           p->ctx->logN, p->ctx->bfv.t);
@@ -190,6 +192,7 @@ extern "C" int mmh_fc_encode_input(const mmh_fc_plan *p, const uint64_t *d_vec, 
 }
 
 extern "C" int mmh_fc_encode_weights(const mmh_fc_plan *p, const uint64_t *d_w, uint64_t *d_pts, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_w && d_pts, MMH_ERR_NULL_POINTER);
   const size_t n_polys = p->n_in * p->n_out;
   KLAUNCH(fc_encode_weights_kernel, n_polys << p->ctx->logN, stream, d_w, d_pts, n_polys, (long)p->meta.rows,
@@ -199,6 +202,7 @@ extern "C" int mmh_fc_encode_weights(const mmh_fc_plan *p, const uint64_t *d_w, 
 
 extern "C" int mmh_fc_encrypt_input(const mmh_fc_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_vec,
                                     const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_sk_ntt && d_vec && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
   void *pts = nullptr;
@@ -272,6 +276,7 @@ extern "C" int mmh_fc_server(const mmh_fc_plan *p, const uint64_t *d_in_cts, con
                              const uint64_t *d_weight_pts, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                              const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                              uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   return fc_server_impl(p, d_in_cts, d_share_pts, d_weight_pts, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                         d_out_share, stream, nullptr, nullptr);
 }
@@ -281,6 +286,7 @@ extern "C" int mmh_fc_server_exact(const mmh_fc_plan *p, const uint64_t *d_in_ct
                                    const uint64_t *d_flood, const int64_t *d_u, const int64_t *d_e0,
                                    const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                                    uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(d_flood && d_e0, MMH_ERR_NULL_POINTER);
   return fc_server_impl(p, d_in_cts, d_share_pts, d_weight_pts, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                         d_out_share, stream, d_flood, d_e0);
@@ -288,6 +294,7 @@ extern "C" int mmh_fc_server_exact(const mmh_fc_plan *p, const uint64_t *d_in_ct
 
 extern "C" int mmh_fc_decrypt(const mmh_fc_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
                               uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
   MMH_REQUIRE(p && d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
   const mmh_ctx *ctx = p->ctx;
   hipStream_t s = (hipStream_t)stream;
@@ -313,6 +320,7 @@ static int bn_counts(const mmh_ctx *ctx, size_t n, size_t *sub_len, size_t *n_ct
 
 extern "C" int mmh_bn_encode_vector(const mmh_ctx *ctx, const uint64_t *d_vec, size_t n, uint64_t *d_pts,
                                     void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   size_t sub, n_ct;
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
   MMH_REQUIRE(d_vec && d_pts, MMH_ERR_NULL_POINTER);
@@ -330,6 +338,7 @@ extern "C" int mmh_bn_encode_vector(const mmh_ctx *ctx, const uint64_t *d_vec, s
 
 extern "C" int mmh_bn_encrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_vec, size_t n,
                                      const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   size_t sub, n_ct;
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
   MMH_REQUIRE(d_sk_ntt && d_vec && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
@@ -366,6 +375,7 @@ static int bn_tail(const mmh_ctx *ctx, const u64 *acc, size_t n, size_t n_ct, si
 extern "C" int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
                              const uint64_t *d_scale_pts, size_t n, const uint64_t *d_random, uint64_t *d_out_cts,
                              uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   size_t sub, n_ct;
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
   MMH_REQUIRE(d_in_cts && d_scale_pts && d_random && d_out_cts && d_out_share, MMH_ERR_NULL_POINTER);
@@ -392,6 +402,7 @@ extern "C" int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const
 extern "C" int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, const uint64_t *d_pts_yx, size_t n,
                                const uint64_t *d_random, uint64_t *d_out_cts, uint64_t *d_out_share,
                                void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   size_t sub, n_ct;
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
   MMH_REQUIRE(d_enc_xy && d_pts_yx && d_random && d_out_cts && d_out_share, MMH_ERR_NULL_POINTER);
@@ -409,6 +420,7 @@ extern "C" int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, con
 
 extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n,
                                      uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   size_t sub, n_ct;
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
   MMH_REQUIRE(d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);
@@ -517,6 +529,7 @@ extern "C" int mmh_bn_tensor_count(const mmh_ctx *ctx, const mmh_bn_tensor_meta 
 
 extern "C" int mmh_bn_encode_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_tensor,
                                     uint64_t *d_pts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   BnTiles g;
   CHECK_RC(bn_tiles(ctx, meta, &g));
   MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
@@ -531,6 +544,7 @@ extern "C" int mmh_bn_encode_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta
 extern "C" int mmh_bn_encrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_sk_ntt,
                                      const uint64_t *d_tensor, const uint64_t *d_a, const int64_t *d_e,
                                      uint64_t *d_cts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   BnTiles g;
   CHECK_RC(bn_tiles(ctx, meta, &g));
   MMH_REQUIRE(d_sk_ntt && d_tensor && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
@@ -548,6 +562,7 @@ extern "C" int mmh_bn_direct_server(const mmh_ctx *ctx, const mmh_bn_tensor_meta
                                     const uint64_t *d_pk_ntt, const int64_t *d_u, const int64_t *d_e0,
                                     const int64_t *d_e1, const uint64_t *d_share1, uint64_t *d_out_cts,
                                     void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   BnTiles g;
   CHECK_RC(bn_tiles(ctx, meta, &g));
   MMH_REQUIRE(d_in_cts && d_scales && d_pk_ntt && d_u && d_e0 && d_e1 && d_share1 && d_out_cts, MMH_ERR_NULL_POINTER);
@@ -597,6 +612,7 @@ extern "C" int mmh_bn_direct_server(const mmh_ctx *ctx, const mmh_bn_tensor_meta
 
 extern "C" int mmh_bn_decrypt_tensor(const mmh_ctx *ctx, const mmh_bn_tensor_meta *meta, const uint64_t *d_sk_ntt,
                                      const uint64_t *d_cts, uint64_t *d_out, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   BnTiles g;
   CHECK_RC(bn_tiles(ctx, meta, &g));
   MMH_REQUIRE(d_sk_ntt && d_cts && d_out, MMH_ERR_NULL_POINTER);

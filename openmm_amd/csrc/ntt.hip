@@ -615,22 +615,26 @@ using namespace mmh;
 
 extern "C" int mmh_ntt_forward(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_t limbs,
                                void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && (d_polys || n_polys == 0), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(limbs >= 1 && limbs <= ctx->L, MMH_ERR_DIM_MISMATCH);
   return ntt_dispatch(ctx, false, d_polys, n_polys, (int)limbs, 0, (hipStream_t)stream);
 }
 extern "C" int mmh_ntt_inverse(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_t limbs,
                                void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && (d_polys || n_polys == 0), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(limbs >= 1 && limbs <= ctx->L, MMH_ERR_DIM_MISMATCH);
   return ntt_dispatch(ctx, true, d_polys, n_polys, (int)limbs, 0, (hipStream_t)stream);
 }
 extern "C" int mmh_ntt_forward_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && (d_polys || n_polys == 0), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
   return ntt_dispatch(ctx, false, d_polys, n_polys, 1, (int)ctx->L, (hipStream_t)stream);
 }
 extern "C" int mmh_ntt_inverse_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && (d_polys || n_polys == 0), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
   return ntt_dispatch(ctx, true, d_polys, n_polys, 1, (int)ctx->L, (hipStream_t)stream);

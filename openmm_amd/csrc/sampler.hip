@@ -122,6 +122,7 @@ extern "C" int mmh_sample_noise(const uint32_t key[8], uint64_t stream_id, int64
 }
 extern "C" int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key[8], uint64_t stream_id,
                                   uint64_t *d_out, size_t n_polys, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && key && (d_out || n_polys == 0), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(lv == 0 || lv == 1, MMH_ERR_INVALID_ARG);
   if (n_polys == 0) return MMH_OK;
@@ -136,6 +137,7 @@ extern "C" int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key
 }
 extern "C" int mmh_signed_to_ntt(const mmh_ctx *ctx, int lv, const int64_t *d_signed, size_t n, uint64_t *d_out,
                                  void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && (n == 0 || (d_signed && d_out)), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(lv == 0 || lv == 1, MMH_ERR_INVALID_ARG);
   if (n == 0) return MMH_OK;

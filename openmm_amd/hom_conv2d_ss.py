@@ -216,8 +216,10 @@ class HomConv2DSS:
     # encodeImage + encodeFilters + conv2DSS as CheetahLinear::conv2d chains them (cheetah-api.cpp:401-445), in one
     # device call from the raw tensors: the server's share [C, H, W] (None when the input is not shared) and the
     # filters [M, C, fh, fw]; bit-identical to the three-call form
-    def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand, inline_verdict=False):
-        """inline_verdict: let the layer call evaluate the zero-filter rule itself (one launch less); the verdict
+    def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand, inline_verdict=False, out=None):
+        """out: optional (out_cts [n_out,2,1,N], out_share out_shape) buffers to write into instead of fresh ones
+        (pre-sized assembly buffers of the sharded form, openmm_amd/sharding.py).
+        inline_verdict: let the layer call evaluate the zero-filter rule itself (one launch less); the verdict
         is then known only when the whole call has run, so the default checks the filters ahead of the call and
         waits for that early verdict alone, which lets the host enqueue the next call meanwhile"""
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
@@ -236,8 +238,13 @@ class HomConv2DSS:
             nz = L.DeferredFlag(bad, negate=True)   # true when no filter is all zero
         self._check_rand(p, rand, ("u", "e1", "mask"))
         u, e1, mask = rand
-        out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
-        out_share = self.ctx._empty(*p.out_shape)
+        if out is None:
+            out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
+            out_share = self.ctx._empty(*p.out_shape)
+        else:
+            out_cts, out_share = out
+            self._need(tuple(out_cts.shape) == (p.n_out, 2, 1, self.ctx.N) and tuple(out_share.shape) == p.out_shape,
+                       3, "conv2DSS: output buffers")
         L.check(self.ctx.lib.mmh_conv_server_tensors(p.handle, L.dptr(img_share0),
                                                      L.dptr(share_tensor if meta.is_shared_input else None),
                                                      L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),

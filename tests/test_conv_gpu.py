@@ -319,8 +319,9 @@ def test_sharded_conv_single_rank_equals_unsharded(mm):
         rand = (smp.ternary(plan.n_out), smp.noise(plan.n_out), smp.uniform(plan.n_out, lv=1)[:, 0].contiguous())
         s1 = srv.encodeImage(share1, meta)
         ref = srv.conv2DSS(cts, s1, srv.encodeFilters(filters, meta), meta, rand)
-        got = ShardedConv(srv, meta).run(cts, s1, filters, lambda n: tuple(r[:n] for r in rand))
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        for mode in ("gather", "d2h"):
+            got = ShardedConv(srv, meta, mode=mode).run(cts, share1, filters, lambda n: tuple(r[:n] for r in rand))
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     finally:
         dist.destroy_process_group()
 

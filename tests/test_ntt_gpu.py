@@ -155,3 +155,36 @@ def test_small_moduli_double_precision_and_integer_paths_agree(mm, N, f64, monke
     d = to_device(ref + qs * (splitmix64(SEED + 6, a.size).reshape(a.shape) % np.uint64(2)))
     g.ntt_inverse(d)
     assert np.array_equal(to_host(d), a)
+
+
+def test_context_calls_leave_the_current_device_alone():
+    """mmh_ctx_create / destroy and every entry point run on the context's device and put the caller's current
+    device back (they used to leave hipSetDevice(device) behind).  With one GPU the switch cannot happen, so the
+    check is that a context for a device that does not exist fails cleanly and changes nothing; with more than
+    one, a context on the last device is used while device 0 is current."""
+    import torch
+    import openmm_amd
+    from openmm_amd.lib import MMHError, to_device, to_host
+    assert torch.cuda.is_available()
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(0)
+    with pytest.raises(MMHError):
+        openmm_amd.Context(4096, (60, 49), 0, device=n_dev)
+    assert torch.cuda.current_device() == 0
+    torch.zeros(1, device="cuda").add_(1)          # the process still works on device 0
+    if n_dev > 1:
+        o = OracleCtx(4096, (60, 49), 0)
+        g = openmm_amd.Context(4096, (60, 49), 0, device=n_dev - 1)
+        assert torch.cuda.current_device() == 0
+        a = np.stack([np.stack([uniform_mod(SEED + l, 4096, q) for l, q in enumerate(o.q)])])
+        d = to_device(a, device=f"cuda:{n_dev - 1}")
+        with torch.cuda.device(n_dev - 1):
+            s = torch.cuda.current_stream().cuda_stream
+        import ctypes as C
+        from openmm_amd.lib import check, dptr
+        check(g.lib.mmh_ntt_forward(g.handle, dptr(d), 1, 2, C.c_void_p(s)))
+        assert torch.cuda.current_device() == 0
+        torch.cuda.synchronize(n_dev - 1)
+        assert np.array_equal(to_host(d), o.ntt_forward(a))
+        g.close()
+        assert torch.cuda.current_device() == 0

@@ -32,14 +32,18 @@ class FakeServer:
         assert filters.shape[0] == meta.n_filters
         return filters
 
-    def conv2DSSFromWeights(self, s0, s1, f, meta, rand):
+    def conv2DSSFromTensors(self, s0, share, f, meta, rand, out=None):
         assert f.shape[0] == meta.n_filters
         m = f.shape[0]
         key = f.reshape(m, -1).sum(1)
         cts = (key[:, None, None] * 7 + torch.arange(self.P.n_spatial)[None, :, None] + rand[0]).expand(m, 3, 8)
         cts = cts.reshape(m * 3, 2, 1, 4).contiguous()
-        share = (key[:, None, None] + torch.arange(20).reshape(1, 4, 5)).contiguous()
-        return cts, share
+        sh = (key[:, None, None] + torch.arange(20).reshape(1, 4, 5)).contiguous()
+        if out is not None:
+            assert tuple(out[0].shape) == tuple(cts.shape) and tuple(out[1].shape) == tuple(sh.shape)
+            out[0].copy_(cts), out[1].copy_(sh)
+            return out
+        return cts, sh
 
 
 def _worker(rank, world, port, n_filters, q):
@@ -51,18 +55,25 @@ def _worker(rank, world, port, n_filters, q):
         filters = torch.arange(n_filters * 2 * 3 * 3, dtype=torch.int64).reshape(n_filters, 2, 3, 3)
         meta = Meta((2, 8, 8), (2, 3, 3), n_filters, 1, 1, True)
         srv = FakeServer()
-        sc = ShardedConv(srv, meta)
-        lo, hi = shard_range(n_filters, world, rank)
-        assert (sc.lo, sc.hi) == (lo, hi)
         s0 = torch.zeros((2, 2, 2, 4), dtype=torch.int64)
-        cts, share = sc.run(s0, s0, filters, lambda n: (5,))
+        ref_cts, ref_share = srv.conv2DSSFromTensors(s0, s0, filters, meta, (5,))
+        ok = []
+        for mode in ("gather", "d2h"):
+            sc = ShardedConv(srv, meta, mode=mode)
+            lo, hi = shard_range(n_filters, world, rank)
+            assert (sc.lo, sc.hi) == (lo, hi)
+            for rep in range(2):          # the assembly buffers are made once and written again by every call
+                cts, share = sc.run(s0, s0, filters, lambda n: (5,))
+                if rank == 0:
+                    ok.append(torch.equal(cts, ref_cts) and torch.equal(share, ref_share))
+                else:
+                    assert cts is None and share is None
         x = torch.arange(1000, dtype=torch.int64)
         y = sharded_elementwise(lambda t: t * 3 + 1, x)
         if rank == 0:
-            ref_cts, ref_share = srv.conv2DSSFromWeights(s0, s0, filters, meta, (5,))
-            q.put((torch.equal(cts, ref_cts), torch.equal(share, ref_share), torch.equal(y, x * 3 + 1)))
+            q.put((all(ok), len(ok) == 4, torch.equal(y, x * 3 + 1)))
         else:
-            assert cts is None and share is None and y is None
+            assert y is None
     finally:
         dist.destroy_process_group()
 
