@@ -65,6 +65,11 @@ int mmh_scratch_release(void);
  * through the driver's bounce buffers).  No counterpart in the reference, whose data never leaves the host. */
 int mmh_host_alloc(void **h_ptr, size_t bytes);
 int mmh_host_free(void *h_ptr);
+/* Page-lock memory the caller already owns (a buffer mapped by several processes, a transport's send buffer) so that
+ * copies to and from it run asynchronously at the link's rate; fails with ERR_SEAL_MEMORY when the driver refuses the
+ * range (the copy then still works, through the driver's bounce buffers).  No counterpart in the reference. */
+int mmh_host_register(void *h_ptr, size_t bytes);
+int mmh_host_unregister(void *h_ptr);
 int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int mmh_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
 int mmh_memset(void *d_dst, int value, size_t bytes, void *stream);

@@ -97,6 +97,7 @@ struct DeviceScope {
   bool switched = false;
   explicit DeviceScope(int device) {
     if (device < 0) return;  // null context: the entry point reports it
+    (void)hipGetLastError();  // an error another library left behind is not this call's: launch checks start clean
     if (hipGetDevice(&prev) != hipSuccess) {
       rc = MMH_ERR_INTERNAL;
       return;

@@ -347,6 +347,24 @@ extern "C" int mmh_host_free(void *h_ptr) {
   MMH_HIP(hipHostFree(h_ptr));
   return MMH_OK;
 }
+extern "C" int mmh_host_register(void *h_ptr, size_t bytes) {
+  MMH_REQUIRE(h_ptr && bytes, MMH_ERR_NULL_POINTER);
+  const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    MMH_FAIL(MMH_ERR_MEMORY, std::string("hipHostRegister -> ") + hipGetErrorString(e));
+  }
+  return MMH_OK;
+}
+extern "C" int mmh_host_unregister(void *h_ptr) {
+  MMH_REQUIRE(h_ptr, MMH_ERR_NULL_POINTER);
+  const hipError_t e = hipHostUnregister(h_ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    MMH_FAIL(MMH_ERR_MEMORY, std::string("hipHostUnregister -> ") + hipGetErrorString(e));
+  }
+  return MMH_OK;
+}
 extern "C" int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream) {
   MMH_REQUIRE((d_dst && src) || bytes == 0, MMH_ERR_NULL_POINTER);
   MMH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));

@@ -35,6 +35,8 @@ SIGNATURES = {
     "mmh_free": [_vp],
     "mmh_host_alloc": [C.POINTER(_vp), _sz],
     "mmh_host_free": [_vp],
+    "mmh_host_register": [_vp, _sz],
+    "mmh_host_unregister": [_vp],
     "mmh_scratch_release": [],
     "mmh_memcpy_h2d": [_vp, _vp, _sz, _vp],
     "mmh_memcpy_d2h": [_vp, _vp, _sz, _vp],

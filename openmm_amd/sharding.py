@@ -79,6 +79,7 @@ class SharedPinned:
     def __init__(self, words, group=None):
         rank = dist.get_rank(group)
         SharedPinned._seq += 1
+        words = (words + 511) // 512 * 512          # whole pages
         name = [f"/dev/shm/mmh_{os.getpid()}_{SharedPinned._seq}" if rank == 0 else None]
         if rank == 0:
             with open(name[0], "wb") as f:
@@ -87,15 +88,17 @@ class SharedPinned:
         self.t = torch.from_file(name[0], shared=True, size=words, dtype=torch.int64)
         self.registered = False
         if torch.cuda.is_available():
-            rc = torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), words * 8, 0)
-            self.registered = int(rc) == 0
+            from . import lib as L
+            self.t.zero_()                          # touch the pages before locking them
+            self.registered = L.load_library().mmh_host_register(L._vp(self.t.data_ptr()), words * 8) == 0
         dist.barrier(group)
         if rank == 0:
             os.unlink(name[0])
 
     def close(self):
         if self.registered:
-            torch.cuda.cudart().cudaHostUnregister(self.t.data_ptr())
+            from . import lib as L
+            L.load_library().mmh_host_unregister(L._vp(self.t.data_ptr()))
             self.registered = False
 
     def __del__(self):
@@ -160,7 +163,7 @@ class ShardedConv:
         host = self._host.t
         n_c, n_s = cts.numel(), share.numel()
         h_cts = host[:self.world * n_c].view(self.world * self.per * n_sp, 2, 1, N)
-        h_share = host[self.world * n_c:].view(self.world * self.per, *share.shape[1:])
+        h_share = host[self.world * n_c:self.world * (n_c + n_s)].view(self.world * self.per, *share.shape[1:])
         h_cts[self.rank * self.per * n_sp:(self.rank + 1) * self.per * n_sp].copy_(cts, non_blocking=True)
         h_share[self.rank * self.per:(self.rank + 1) * self.per].copy_(share, non_blocking=True)
         if cts.is_cuda:
