@@ -32,6 +32,15 @@ class CheetahLinear {
 
   void conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<Tensor<uint64_t>> &filters,
               const ConvMeta &meta, Tensor<uint64_t> &out_tensor) const;
+  // conv2d as Conv2DWrapper needs it (library_fixed_uniform_cheetah.cpp:216-300): activations [H][W][CI], filters
+  // [FH][FW][CI][CO] (server only) and the result [OH][OW][CO] in the networks' own layouts, raw values (getRingElt is
+  // applied on the device); no host-side repacking, no intermediate tensors.  Not in the reference class.
+  // expect_oh / expect_ow (when not 0): the output size the caller's array was made for; a layer whose geometry
+  // gives another size throws before anything is written.
+  void conv2d_nhwc(const uint64_t *input_nhwc, const uint64_t *filters_hwio, const ConvMeta &meta,
+                   uint64_t *out_nhwc, int64_t expect_oh = 0, int64_t expect_ow = 0) const;
+  // idle device buffers of this object back to the driver (it keeps a size-keyed pool, capped at 2 GiB idle)
+  void release_device_buffers() const;
   void fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
           Tensor<uint64_t> &out_vec_share) const;
   void bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &scale_vector, const BNMeta &meta,

@@ -7,6 +7,7 @@
 // implementations below are test doubles (LoopbackIO; IdealCOT in the style of
 // SCI/src/OT/ideal.h:106-156).
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <algorithm>
@@ -28,14 +29,30 @@ class IOChannel {
   uint64_t counter = 0;  // bytes sent, as sci::IOChannel::counter (io_channel.h:41-45)
 };
 
-// One direction of an in-process byte pipe: a queue of message chunks copied at memcpy speed.
+// One direction of an in-process byte pipe.  A receiver that is already waiting gets the sender's bytes copied
+// straight into its buffer (one copy, like a socket read into user memory); otherwise the message is queued in a
+// chunk (recycled: a fresh 100-MiB vector would fault its pages in on every layer) and copied out later.
 class BytePipe {
  public:
   void push(const void *p, size_t n) {
     if (n == 0) return;
     const uint8_t *b = static_cast<const uint8_t *>(p);
-    std::vector<uint8_t> chunk(b, b + n);
-    std::lock_guard<std::mutex> g(m_);
+    std::unique_lock<std::mutex> g(m_);
+    if (want_ && q_.empty()) {  // direct hand-over into the waiting receiver's buffer
+      const size_t take = std::min(n, want_);
+      timed_copy(dst_, b, take);
+      dst_ += take, want_ -= take, b += take, n -= take;
+      if (want_ == 0) cv_.notify_all();
+      if (n == 0) return;
+    }
+    std::vector<uint8_t> chunk;
+    if (!spare_.empty()) {
+      chunk = std::move(spare_.back());
+      spare_.pop_back();
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    chunk.assign(b, b + n);
+    copy_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     bytes_ += n;
     q_.push_back(std::move(chunk));
     cv_.notify_all();
@@ -43,25 +60,47 @@ class BytePipe {
   void pop(void *p, size_t n) {
     uint8_t *dst = static_cast<uint8_t *>(p);
     std::unique_lock<std::mutex> g(m_);
-    cv_.wait(g, [&] { return bytes_ >= n; });
-    bytes_ -= n;
     while (n > 0) {
+      if (q_.empty()) {  // nothing queued: post the buffer and let the sender fill it
+        dst_ = dst, want_ = n;
+        cv_.wait(g, [&] { return want_ == 0 || !q_.empty(); });
+        const size_t got = n - want_;
+        dst += got, n -= got;
+        want_ = 0, dst_ = nullptr;
+        continue;
+      }
       std::vector<uint8_t> &front = q_.front();
       const size_t take = std::min(n, front.size() - head_);
-      std::memcpy(dst, front.data() + head_, take);
-      dst += take, n -= take, head_ += take;
+      timed_copy(dst, front.data() + head_, take);
+      dst += take, n -= take, head_ += take, bytes_ -= take;
       if (head_ == front.size()) {
+        if (spare_.size() < 4) spare_.push_back(std::move(front));
         q_.pop_front();
         head_ = 0;
       }
     }
   }
+  // nanoseconds this pipe has spent copying bytes (the stand-in for the network between the parties), so that a
+  // measurement can tell the transport from the work on either side
+  uint64_t copy_ns() {
+    std::lock_guard<std::mutex> g(m_);
+    return copy_ns_;
+  }
 
  private:
+  void timed_copy(void *d, const void *s, size_t n) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::memcpy(d, s, n);
+    copy_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+  uint64_t copy_ns_ = 0;
   std::mutex m_;
   std::condition_variable cv_;
   std::deque<std::vector<uint8_t>> q_;
-  size_t head_ = 0, bytes_ = 0;  // read offset inside the front chunk, bytes queued
+  std::vector<std::vector<uint8_t>> spare_;  // emptied chunks kept for reuse
+  size_t head_ = 0, bytes_ = 0;              // read offset inside the front chunk, bytes queued
+  uint8_t *dst_ = nullptr;                   // a receiver's posted buffer and what it still needs
+  size_t want_ = 0;
 };
 
 class LoopbackIO : public IOChannel {
@@ -76,6 +115,7 @@ class LoopbackIO : public IOChannel {
     counter += n;
   }
   void recv_data(void *d, size_t n) override { rx_->pop(d, n); }
+  uint64_t transport_ns() const { return tx_->copy_ns() + rx_->copy_ns(); }  // both directions of the pair
 
  private:
   std::shared_ptr<BytePipe> tx_, rx_;

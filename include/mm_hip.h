@@ -65,6 +65,12 @@ int mmh_scratch_release(void);
  * through the driver's bounce buffers).  No counterpart in the reference, whose data never leaves the host. */
 int mmh_host_alloc(void **h_ptr, size_t bytes);
 int mmh_host_free(void *h_ptr);
+/* The current device and streams for C/C++ callers that do not link HIP: a host object creates one stream, enqueues
+ * its copies and layer calls on it and waits once (mmh_stream_sync) before it hands bytes to the network. */
+int mmh_get_device(int *device);
+int mmh_set_device(int device);
+int mmh_stream_create(void **stream);
+int mmh_stream_destroy(void *stream);
 /* Page-lock memory the caller already owns (a buffer mapped by several processes, a transport's send buffer) so that
  * copies to and from it run asynchronously at the link's rate; fails with ERR_SEAL_MEMORY when the driver refuses the
  * range (the copy then still works, through the driver's bounce buffers).  No counterpart in the reference. */
@@ -484,6 +490,30 @@ int mmh_b2a_post(int party, const uint8_t *d_x, const uint64_t *d_y, size_t n, i
  * CheetahLinear::BOLE (cheetah-api.cpp:648-649; sci::moduloMult utils.hpp:353-363) */
 int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const uint64_t *d_y, size_t n, uint64_t p,
                         void *stream);
+
+/* Layout changes of the layer adapters on the device (SCI/src/library_fixed_uniform_cheetah.cpp:236-262 filters
+ * [FH][FW][CI][CO] -> per filter [CI][FH][FW]; :284-287 input [H][W][CI] -> [CI][H][W]; :293-299 output back), with
+ * getRingElt's reduction `& ring_mask` on the way in.  Out of place. */
+int mmh_repack_nhwc_to_chw(const uint64_t *d_in, size_t h, size_t w, size_t c, uint64_t ring_mask, uint64_t *d_out,
+                           void *stream);
+int mmh_repack_chw_to_nhwc(const uint64_t *d_in, size_t c, size_t h, size_t w, uint64_t *d_out, void *stream);
+int mmh_repack_hwio_to_oihw(const uint64_t *d_in, size_t fh, size_t fw, size_t ci, size_t co, uint64_t ring_mask,
+                            uint64_t *d_out, void *stream);
+
+/* FusedBN of the shipped networks (USE_FUSED_BN 1; networks/main_resnet50.cpp:1728-1788): the server
+ * folds a batch-norm scale into the filters before Conv2DWrapper: scaled = neg_mod(round(f/2^k * s/2^k * 2^k), 2^l)
+ * in double arithmetic with getSignValue (:21-28) on both operands -- the only floating point on the path, evaluated
+ * in the reference's order so the bits agree.  d_filters [fh][fw][ci][co], d_scales [co]; d_out in the same layout
+ * (oihw = 0, what FusedBN hands to Conv2DWrapper) or as [co][ci][fh][fw] (oihw = 1, what mmh_conv_server_tensors /
+ * mmh_conv_filters_prepare read).  *d_any_nonzero (device word) becomes 1 unless every scaled entry is zero, the
+ * case in which the reference warns and exits (:1754-1762); the caller reads it back.  Products beyond int64_t are
+ * undefined in the reference (static_cast of the double) and unspecified here. */
+int mmh_fused_bn_filters(const uint64_t *d_filters, const uint64_t *d_scales, int fh, int fw, int ci, int co,
+                         int bitlength, int k_scale, uint64_t prime_mod, int oihw, uint64_t *d_out,
+                         uint32_t *d_any_nonzero, void *stream);
+/* the bias the server adds to its output share afterwards (:1771-1786): out[pixel][m] += bias[m] << k (ScaleUp1 in the
+ * SCI_OT build, library_fixed_uniform.cpp:1394-1402; SecretAdd :1861-1867), NHWC */
+int mmh_fused_bn_bias(uint64_t *d_out_nhwc, const uint64_t *d_bias, size_t pixels, int co, int k_scale, void *stream);
 
 /* ---- COT post-processing: what SilentOT does between Ferret's output and the values the
  * conversions above consume.  One launch per side: MITCCRH hash of the Ferret blocks (AES-128 under one fresh

@@ -347,6 +347,29 @@ extern "C" int mmh_host_free(void *h_ptr) {
   MMH_HIP(hipHostFree(h_ptr));
   return MMH_OK;
 }
+extern "C" int mmh_get_device(int *device) {
+  MMH_REQUIRE(device, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipGetDevice(device));
+  return MMH_OK;
+}
+extern "C" int mmh_set_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    MMH_FAIL(MMH_ERR_CONFIG, "hipSetDevice(" + std::to_string(device) + ") failed");
+  }
+  return MMH_OK;
+}
+extern "C" int mmh_stream_create(void **stream) {
+  MMH_REQUIRE(stream, MMH_ERR_NULL_POINTER);
+  hipStream_t s = nullptr;
+  MMH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void *)s;
+  return MMH_OK;
+}
+extern "C" int mmh_stream_destroy(void *stream) {
+  if (stream) MMH_HIP(hipStreamDestroy((hipStream_t)stream));
+  return MMH_OK;
+}
 extern "C" int mmh_host_register(void *h_ptr, size_t bytes) {
   MMH_REQUIRE(h_ptr && bytes, MMH_ERR_NULL_POINTER);
   const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);

@@ -204,6 +204,74 @@ static int check_common(int party, size_t n, const void *a, const void *b, const
   MMH_REQUIRE(n <= 0x7fffffffull * 256, MMH_ERR_OUT_BOUND);
   return MMH_OK;
 }
+// FusedBN filter scaling (networks/main_resnet50.cpp:1736-1753): scaled = round(f/2^k * s/2^k * 2^k) in double
+// arithmetic, exactly as written (the division by 2^k and the last product are exact; the middle product rounds to
+// nearest, as v_mul_f64 does; no addition follows a product, so nothing can contract into an FMA), then sci::neg_mod.
+// One thread per filter entry; OIHW = 1 writes [co][ci][fh][fw] (what the conv entry points read), else the
+// reference's [fh][fw][ci][co].  *any_nonzero becomes 1 when some scaled entry is not zero (:1754).
+#pragma clang fp contract(off)
+__device__ __forceinline__ long long sign_value(u64 x, int bitlength) {  // getSignValue, main_resnet50.cpp:21-28
+  const long long upper = 1ll << bitlength;
+  const u64 mask = (u64)upper - 1, half = (u64)upper >> 1;
+  x &= mask;
+  return (long long)(x >= half ? x - (u64)upper : x);
+}
+__global__ __launch_bounds__(256) void fused_bn_filters_kernel(const u64 *__restrict__ filters,
+                                                               const u64 *__restrict__ scales, size_t total, int fh,
+                                                               int fw, int ci, int co, int bitlength, double scale,
+                                                               long long prime_mod, int oihw, u64 *__restrict__ out,
+                                                               u32 *__restrict__ any_nonzero) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int nz = 0;
+  if (idx < total) {
+    const int m = (int)(idx % co);
+    const double bn_scale = (double)sign_value(scales[m], bitlength) / scale;
+    const double fval = (double)sign_value(filters[idx], bitlength) / scale;
+    const long long f64 = (long long)round(fval * bn_scale * scale);
+    const u64 v = (u64)(((f64 % prime_mod) + prime_mod) % prime_mod);
+    size_t o = idx;
+    if (oihw) {
+      const size_t r = idx / co;  // (h*fw + w)*ci + c
+      const int c = (int)(r % ci);
+      const size_t hw = r / ci;
+      o = ((size_t)m * ci + c) * ((size_t)fh * fw) + hw;
+    }
+    out[o] = v;
+    nz = v != 0;
+  }
+  if (__syncthreads_or(nz) && threadIdx.x == 0) atomicOr(any_nonzero, 1u);
+}
+// :1771-1786: out[p][m] += bias[m] << k (ScaleUp in the SCI_OT build, then SecretAdd = wrapping add)
+__global__ __launch_bounds__(256) void fused_bn_bias_kernel(u64 *__restrict__ out, const u64 *__restrict__ bias,
+                                                            size_t total, int co, int k_scale) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) out[idx] += bias[idx % co] << k_scale;
+}
+// Layout changes of the layer adapters (SCI/src/library_fixed_uniform_cheetah.cpp:236-262, :284-299): the networks
+// keep activations as [H][W][C] and filters as [FH][FW][CI][CO]; HomConv2DSS wants [C][H][W] and [CO][CI][FH][FW],
+// entries reduced into the ring (getRingElt: & (2^l - 1)).  One thread per OUTPUT element (coalesced writes; the
+// strided reads of a few MiB are served by the L2).
+__global__ __launch_bounds__(256) void nhwc_to_chw_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                          size_t hw, size_t c, u64 mask) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= hw * c) return;
+  const size_t ch = idx / hw, p = idx % hw;
+  out[idx] = in[p * c + ch] & mask;
+}
+__global__ __launch_bounds__(256) void chw_to_nhwc_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                          size_t hw, size_t c) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= hw * c) return;
+  const size_t p = idx / c, ch = idx % c;
+  out[idx] = in[ch * hw + p];
+}
+__global__ __launch_bounds__(256) void hwio_to_oihw_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                           size_t hw, size_t ci, size_t co, u64 mask) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= hw * ci * co) return;
+  const size_t p = idx % hw, r = idx / hw, c = r % ci, m = r / ci;
+  out[idx] = in[(p * ci + c) * co + m] & mask;
+}
 }  // namespace mmh
 
 using namespace mmh;
@@ -367,5 +435,50 @@ extern "C" int mmh_bole_cross_term(uint64_t *d_out, const uint64_t *d_x, const u
   MMH_REQUIRE(p >= 2 && p < (u64(1) << 62), MMH_ERR_INVALID_ARG);
   const unsigned __int128 ratio = p & (p - 1) ? ~(unsigned __int128)0 / p : (~(unsigned __int128)0 / p) + 1;
   LAUNCH1D(cross_term_kernel, n, stream, d_out, d_x, d_y, n, p, (u64)(ratio >> 64), (u64)ratio);
+  return MMH_OK;
+}
+
+extern "C" int mmh_fused_bn_filters(const uint64_t *d_filters, const uint64_t *d_scales, int fh, int fw, int ci, int co,
+                                    int bitlength, int k_scale, uint64_t prime_mod, int oihw, uint64_t *d_out,
+                                    uint32_t *d_any_nonzero, void *stream) {
+  MMH_REQUIRE(d_filters && d_scales && d_out && d_any_nonzero, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(fh > 0 && fw > 0 && ci > 0 && co > 0, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(bitlength >= 2 && bitlength <= 62 && k_scale >= 0 && k_scale < bitlength, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(prime_mod >= 2 && prime_mod < (uint64_t(1) << 62), MMH_ERR_INVALID_ARG);  // neg_mod works in int64_t
+  MMH_REQUIRE(d_out != d_filters || !oihw, MMH_ERR_INVALID_ARG);                       // the transposing form is out of place
+  const size_t total = (size_t)fh * fw * ci * co;
+  MMH_HIP(hipMemsetAsync(d_any_nonzero, 0, 4, (hipStream_t)stream));
+  LAUNCH1D(fused_bn_filters_kernel, total, stream, d_filters, d_scales, total, fh, fw, ci, co, bitlength,
+           (double)(uint64_t(1) << k_scale), (long long)prime_mod, oihw, d_out, d_any_nonzero);
+  return MMH_OK;
+}
+
+extern "C" int mmh_fused_bn_bias(uint64_t *d_out_nhwc, const uint64_t *d_bias, size_t pixels, int co, int k_scale,
+                                 void *stream) {
+  MMH_REQUIRE(d_out_nhwc && d_bias, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(co > 0 && k_scale >= 0 && k_scale < 64, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(fused_bn_bias_kernel, pixels * (size_t)co, stream, d_out_nhwc, d_bias, pixels * (size_t)co, co, k_scale);
+  return MMH_OK;
+}
+
+extern "C" int mmh_repack_nhwc_to_chw(const uint64_t *d_in, size_t h, size_t w, size_t c, uint64_t ring_mask,
+                                      uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(d_in != d_out, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(nhwc_to_chw_kernel, h * w * c, stream, d_in, d_out, h * w, c, ring_mask);
+  return MMH_OK;
+}
+extern "C" int mmh_repack_chw_to_nhwc(const uint64_t *d_in, size_t c, size_t h, size_t w, uint64_t *d_out,
+                                      void *stream) {
+  MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(d_in != d_out, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(chw_to_nhwc_kernel, h * w * c, stream, d_in, d_out, h * w, c);
+  return MMH_OK;
+}
+extern "C" int mmh_repack_hwio_to_oihw(const uint64_t *d_in, size_t fh, size_t fw, size_t ci, size_t co,
+                                       uint64_t ring_mask, uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(d_in && d_out, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(d_in != d_out, MMH_ERR_INVALID_ARG);
+  LAUNCH1D(hwio_to_oihw_kernel, fh * fw * ci * co, stream, d_in, d_out, fh * fw, ci, co, ring_mask);
   return MMH_OK;
 }

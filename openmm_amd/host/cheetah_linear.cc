@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <array>
+#include <functional>
+#include <iterator>
 #include <map>
 #include <mutex>
 
@@ -41,12 +43,15 @@ void must(int rc, const char *what) {
     throw std::runtime_error(std::string(what) + " [" + CodeMessage(static_cast<Code>(rc)) + "] " + mmh_last_error());
 }
 
-// Device buffers are recycled by size: a layer call needs a dozen of them and hipMalloc / hipFree cost
-// 0.1-0.3 ms each.  Everything here runs on the null stream, which orders a buffer's next use after its last.
+// Device buffers are recycled by size, per object (hence per device): a layer call needs a dozen of them and
+// hipMalloc / hipFree cost 0.1-0.3 ms each.  All work of an object runs on its one stream, which orders a buffer's
+// next use after its last.  Idle blocks beyond `cap_bytes` go back to the driver (largest first); release() frees
+// all idle blocks.
 struct DevPool {
   std::mutex mu;
   std::multimap<size_t, uint64_t *> free_;
-  // never freed: the pool lives until process exit, when the HIP runtime may already be gone
+  size_t idle_bytes = 0, cap_bytes = size_t(2) << 30;
+  ~DevPool() { release(); }
   uint64_t *get(size_t words) {
     {
       std::lock_guard<std::mutex> g(mu);
@@ -54,46 +59,56 @@ struct DevPool {
       if (it != free_.end()) {
         uint64_t *p = it->second;
         free_.erase(it);
+        idle_bytes -= words * 8;
         return p;
       }
     }
     void *q = nullptr;
-    must(mmh_malloc(&q, (words ? words : 1) * 8), "mmh_malloc");
+    if (mmh_malloc(&q, (words ? words : 1) * 8) != MMH_OK) {  // give the idle blocks back and try once more
+      release();
+      must(mmh_malloc(&q, (words ? words : 1) * 8), "mmh_malloc");
+    }
     return static_cast<uint64_t *>(q);
   }
   void put(uint64_t *p, size_t words) {
     if (!p) return;
     std::lock_guard<std::mutex> g(mu);
     free_.emplace(words, p);
+    idle_bytes += words * 8;
+    while (idle_bytes > cap_bytes && !free_.empty()) {  // callers sync their stream before buffers die
+      auto it = std::prev(free_.end());
+      idle_bytes -= it->first * 8;
+      (void)mmh_free(it->second);
+      free_.erase(it);
+    }
+  }
+  void release() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto &kv : free_) (void)mmh_free(kv.second);
+    free_.clear();
+    idle_bytes = 0;
   }
 };
-DevPool &dev_pool() {
-  static DevPool pool;
-  return pool;
-}
 
-// device buffer of 64-bit words
+// device buffer of 64-bit words, taken from and returned to its object's pool
 struct Dev {
+  DevPool *pool = nullptr;
   uint64_t *p = nullptr;
   size_t n = 0;
   Dev() = default;
-  explicit Dev(size_t words) { alloc(words); }
+  Dev(DevPool *pl, size_t words) : pool(pl), p(pl->get(words)), n(words) {}
   Dev(const Dev &) = delete;
-  Dev(Dev &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
-  ~Dev() { dev_pool().put(p, n); }
-  void alloc(size_t words) {
-    dev_pool().put(p, n);
-    p = nullptr;
-    n = words;
-    p = dev_pool().get(words);
+  Dev(Dev &&o) noexcept : pool(o.pool), p(o.p), n(o.n) { o.p = nullptr; }
+  Dev &operator=(Dev &&o) noexcept {
+    if (this != &o) {
+      if (p) pool->put(p, n);
+      pool = o.pool, p = o.p, n = o.n;
+      o.p = nullptr;
+    }
+    return *this;
   }
-  void upload(const uint64_t *src, size_t words) {
-    must(mmh_memcpy_h2d(p, src, words * 8, nullptr), "h2d");
-    must(mmh_stream_sync(nullptr), "sync");
-  }
-  void download(uint64_t *dst, size_t words) const {
-    must(mmh_memcpy_d2h(dst, p, words * 8, nullptr), "d2h");
-    must(mmh_stream_sync(nullptr), "sync");
+  ~Dev() {
+    if (p) pool->put(p, n);
   }
 };
 
@@ -101,10 +116,29 @@ struct Keys {  // one BFV context with the party's key material on the device
   mmh_ctx *ctx = nullptr;
   Dev sk, pk, pk_last, sk_last;  // sk [L][N] (BOB), pk [2][L][N] (ALICE), restrictions to the last level
 };
+
+// the object's device is current inside its methods and the caller's afterwards
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    must(mmh_get_device(&prev), "mmh_get_device");
+    if (prev != device) {
+      must(mmh_set_device(device), "mmh_set_device");
+      switched = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)mmh_set_device(prev);
+  }
+};
 }  // namespace
 
 struct CheetahLinear::Impl {
   static constexpr size_t N = 4096, L = 2;
+  int device = 0;
+  void *stream = nullptr;  // every copy and kernel of this object; one wait before bytes go to the channel
+  mutable DevPool pool;
   Keys ring, field;
   uint32_t key[8];
   mutable uint64_t stream_id = 1;
@@ -116,11 +150,24 @@ struct CheetahLinear::Impl {
   mutable std::map<std::array<int64_t, 3>, mmh_fc_plan *> fc_plans;
 
   ~Impl() {
+    if (stream) (void)mmh_stream_sync(stream);
     for (auto &kv : conv_plans) mmh_conv_plan_destroy(kv.second);
     for (auto &kv : fc_plans) mmh_fc_plan_destroy(kv.second);
     mmh_ctx_destroy(ring.ctx);
     mmh_ctx_destroy(field.ctx);
+    if (staging.p) mmh_host_free(staging.p);
+    if (flag_host) mmh_host_free(flag_host);
+    mmh_stream_destroy(stream);
+  }  // the key buffers return to the pool and the pool frees its blocks as the members go (hipFree needs no stream)
+  Dev mk(size_t words) const { return Dev(&pool, words); }
+  void up(const Dev &d, const uint64_t *src, size_t words) const {  // asynchronous; src may be reused on return
+    must(mmh_memcpy_h2d(d.p, src, words * 8, stream), "h2d");
   }
+  void down(uint64_t *dst, const Dev &d, size_t words) const {  // valid after sync()
+    must(mmh_memcpy_d2h(dst, d.p, words * 8, stream), "d2h");
+  }
+  void sync() const { must(mmh_stream_sync(stream), "sync"); }
+
   mmh_conv_plan *conv_plan(const mmh_conv_meta &m) const {
     const std::array<int64_t, 9> key{m.in_c, m.in_h, m.in_w, m.f_h, m.f_w, m.n_filters, m.padding_same, m.stride,
                                      m.is_shared_input};
@@ -144,41 +191,42 @@ struct CheetahLinear::Impl {
 
   // ---- randomness (device ChaCha20 keyed from the OS) ----
   Dev uniform(const mmh_ctx *c, int lv, size_t n) const {
-    Dev d(n * (lv == 0 ? L : 1) * N);
-    must(mmh_sample_uniform(c, lv, key, sid(), d.p, n, nullptr), "sample_uniform");
+    Dev d = mk(n * (lv == 0 ? L : 1) * N);
+    must(mmh_sample_uniform(c, lv, key, sid(), d.p, n, stream), "sample_uniform");
     return d;
   }
   Dev ternary(size_t n) const {
-    Dev d(n * N);
-    must(mmh_sample_ternary(key, sid(), (int64_t *)d.p, n * N, nullptr), "sample_ternary");
+    Dev d = mk(n * N);
+    must(mmh_sample_ternary(key, sid(), (int64_t *)d.p, n * N, stream), "sample_ternary");
     return d;
   }
   Dev noise(size_t n) const {
-    Dev d(n * N);
-    must(mmh_sample_noise(key, sid(), (int64_t *)d.p, n * N, nullptr), "sample_noise");
+    Dev d = mk(n * N);
+    must(mmh_sample_noise(key, sid(), (int64_t *)d.p, n * N, stream), "sample_noise");
     return d;
   }
   Dev words(size_t n) const {
-    Dev d(n);
-    must(mmh_chacha20_words(key, sid(), 0, d.p, n, nullptr), "chacha20");
+    Dev d = mk(n);
+    must(mmh_chacha20_words(key, sid(), 0, d.p, n, stream), "chacha20");
     return d;
   }
 
   // ---- keys: BOB generates and sends pk, ALICE receives (cheetah-api.cpp:107-141, :164-196) ----
   void setup_keys(Keys &k, int party) {
     std::vector<uint64_t> host(2 * L * N);
-    k.pk.alloc(2 * L * N);
-    k.pk_last.alloc(2 * N);
+    k.pk = mk(2 * L * N);
+    k.pk_last = mk(2 * N);
     if (party == kBob) {
-      k.sk.alloc(L * N);
-      k.sk_last.alloc(N);
+      k.sk = mk(L * N);
+      k.sk_last = mk(N);
       Dev s = ternary(1), a = uniform(k.ctx, 0, 1), e = noise(1);
-      must(mmh_signed_to_ntt(k.ctx, 0, (const int64_t *)s.p, 1, k.sk.p, nullptr), "keygen");
-      must(mmh_make_public_key(k.ctx, k.sk.p, a.p, (const int64_t *)e.p, k.pk.p, nullptr), "create_public_key");
-      k.pk.download(host.data(), host.size());
+      must(mmh_signed_to_ntt(k.ctx, 0, (const int64_t *)s.p, 1, k.sk.p, stream), "keygen");
+      must(mmh_make_public_key(k.ctx, k.sk.p, a.p, (const int64_t *)e.p, k.pk.p, stream), "create_public_key");
       std::vector<uint64_t> skh(L * N);
-      k.sk.download(skh.data(), skh.size());
-      k.sk_last.upload(skh.data(), N);
+      down(host.data(), k.pk, host.size());
+      down(skh.data(), k.sk, skh.size());
+      sync();
+      up(k.sk_last, skh.data(), N);
       uint64_t sz = host.size() * 8;
       io->send_data(&sz, sizeof(sz));
       io->send_data(host.data(), sz);
@@ -188,27 +236,26 @@ struct CheetahLinear::Impl {
       io->recv_data(&sz, sizeof(sz));
       if (sz != host.size() * 8) throw std::runtime_error("CheetahLinear: public key size mismatch");
       io->recv_data(host.data(), sz);
-      k.pk.upload(host.data(), host.size());
+      up(k.pk, host.data(), host.size());
     }
     // pk restricted to the last level {q0}: limb 0 of both polynomials
     std::vector<uint64_t> last(2 * N);
     std::copy(host.begin(), host.begin() + N, last.begin());
     std::copy(host.begin() + L * N, host.begin() + L * N + N, last.begin() + N);
-    k.pk_last.upload(last.data(), last.size());
+    up(k.pk_last, last.data(), last.size());
+    sync();
   }
 
   // ---- ciphertext transport: u32 count, then the raw coefficient words (cheetah-api.cpp:11-29) ----
-  // host staging for ciphertext batches (up to 128 MiB per layer): one grow-only buffer per object, so the
-  // pages are touched once and not on every call
-  // (page-locked: the copies run at the link's rate and the pages are never touched by the host first)
+  // Host staging for ciphertext batches (up to 128 MiB per layer): one grow-only page-locked buffer per object, so
+  // copies run asynchronously at the link's rate and the pages are touched once, not on every call.  Every public
+  // method ends with the stream drained, so the buffer is free when the next call starts.
   struct Pinned {
     uint64_t *p = nullptr;
     size_t words = 0;
-    ~Pinned() {
-      if (p) mmh_host_free(p);
-    }
   };
   mutable Pinned staging;
+  mutable uint32_t *flag_host = nullptr;
   uint64_t *stage(size_t words) const {
     if (staging.words < words) {
       if (staging.p) mmh_host_free(staging.p);
@@ -219,25 +266,69 @@ struct CheetahLinear::Impl {
     }
     return staging.p;
   }
-  void send_cts(const Dev &d, size_t n_cts, size_t words_per_ct) const {
-    const size_t words = n_cts * words_per_ct;
-    uint64_t *host = stage(words);
-    d.download(host, words);
+  // enqueue the copy of a batch to the staging buffer; after sync(), send_staged() puts it on the wire
+  void stage_cts(const Dev &d, size_t words) const { down(stage(words), d, words); }
+  void send_staged(size_t n_cts, size_t words_per_ct) const {
     uint32_t n = (uint32_t)n_cts;
     io->send_data(&n, sizeof(n));
-    io->send_data(host, words * 8);
+    io->send_data(staging.p, n_cts * words_per_ct * 8);
     io->flush();
   }
-  Dev recv_cts(size_t expect, size_t words_per_ct) const {
+  Dev recv_cts(size_t expect, size_t words_per_ct) const {  // waits for the peer, then copies asynchronously
     uint32_t n = 0;
     io->recv_data(&n, sizeof(n));
     if (n != expect) throw std::runtime_error("CheetahLinear: ciphertext count mismatch");
     const size_t words = (size_t)n * words_per_ct;
     uint64_t *host = stage(words);
     io->recv_data(host, words * 8);
-    Dev d(words);
-    d.upload(host, words);
+    Dev d = mk(words);
+    up(d, host, words);
     return d;
+  }
+
+  // conv2DOneFilter's zero-filter verdict (hom_conv2d_ss.cc:573-580), written by the layer call on the device
+  uint32_t *zero_flag_host() const {
+    if (!flag_host) {
+      void *q = nullptr;
+      must(mmh_host_alloc(&q, 64), "mmh_host_alloc");
+      flag_host = static_cast<uint32_t *>(q);
+    }
+    return flag_host;
+  }
+
+  // CheetahLinear::conv2d on device-resident tensors: d_img [C][H][W] reduced into the ring, d_filters
+  // [M][C][fh][fw] (ALICE); the share / decrypted tensor [M][oh][ow] is left in d_out.  Ends with the stream drained.
+  void conv_core(int party, const ConvMeta &meta, mmh_conv_plan *plan, size_t n_in, size_t n_out, const Dev &d_img,
+                 const Dev *d_filters, const Dev &d_out, const std::function<void()> &before_wait) const {
+    if (party == kBob) {
+      Dev a = uniform(ring.ctx, 0, n_in), e = noise(n_in), cts = mk(n_in * 2 * L * N);
+      must(mmh_conv_encrypt_image(plan, ring.sk.p, d_img.p, a.p, (const int64_t *)e.p, cts.p, stream),
+           "CheetahLinear::conv2d encryptImage");
+      stage_cts(cts, n_in * 2 * L * N);
+      sync();
+      send_staged(n_in, 2 * L * N);
+      Dev res = recv_cts(n_out, 2 * N);
+      must(mmh_conv_decrypt(plan, ring.sk_last.p, res.p, d_out.p, stream), "CheetahLinear::conv2d decryptToTensor");
+      before_wait();
+      sync();
+    } else {
+      // randomness and the flag are enqueued before the (blocking) receive, so they run while the client encrypts
+      Dev u = ternary(n_out), e1 = noise(n_out), mask = uniform(ring.ctx, 1, n_out);
+      Dev out_cts = mk(n_out * 2 * N), flag = mk(1);
+      Dev cts = recv_cts(n_in, 2 * L * N);
+      // encodeImage + encodeFilters + conv2DSS (cheetah-api.cpp:401-445) in one device call
+      must(mmh_conv_server_tensors(plan, cts.p, meta.is_shared_input ? d_img.p : nullptr, d_filters->p, ring.pk_last.p,
+                                   (const int64_t *)u.p, (const int64_t *)e1.p, mask.p, out_cts.p, d_out.p,
+                                   (uint32_t *)flag.p, stream),
+           "CheetahLinear::conv2d conv2DSS:");
+      uint32_t *verdict = zero_flag_host();
+      must(mmh_memcpy_d2h(verdict, flag.p, 4, stream), "d2h");
+      stage_cts(out_cts, n_out * 2 * N);
+      before_wait();
+      sync();
+      if (*verdict) throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
+      send_staged(n_out, 2 * N);
+    }
   }
 };
 
@@ -247,12 +338,15 @@ CheetahLinear::CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, si
     throw std::logic_error("CheetahLinear: base_mod out-of-bound [2, 2^45)");
   if (party != kAlice && party != kBob) throw std::invalid_argument("CheetahLinear: party");
   impl_->io = io;
+  impl_->device = device;
   FILE *f = std::fopen("/dev/urandom", "rb");
   if (!f || std::fread(impl_->key, 1, sizeof(impl_->key), f) != sizeof(impl_->key)) {
     if (f) std::fclose(f);
     throw std::runtime_error("CheetahLinear: cannot seed the sampler");
   }
   std::fclose(f);
+  DeviceGuard dg(device);
+  must(mmh_stream_create(&impl_->stream), "stream");
   const int bits[2] = {60, 49};  // :99-103
   must(mmh_ctx_create_bits(&impl_->ring.ctx, Impl::N, bits, 2, base_mod, device), "SEALContext");
   impl_->setup_keys(impl_->ring, party);
@@ -265,6 +359,12 @@ CheetahLinear::CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, si
 
 CheetahLinear::~CheetahLinear() = default;
 
+void CheetahLinear::release_device_buffers() const {
+  DeviceGuard dg(impl_->device);
+  impl_->sync();
+  impl_->pool.release();
+}
+
 void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<Tensor<uint64_t>> &filters,
                            const ConvMeta &meta, Tensor<uint64_t> &out_tensor) const {
   if (!meta.ishape.IsSameSize(in_tensor.shape())) throw std::invalid_argument("CheetahLinear::conv2d meta.ishape mismatch");
@@ -272,7 +372,7 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
   for (const auto &f : filters)
     if (!meta.fshape.IsSameSize(f.shape())) throw std::invalid_argument("CheetahLinear::conv2d meta.fshape mismatch");
   const Impl &I = *impl_;
-  const size_t N = Impl::N, L = Impl::L;
+  DeviceGuard dg(I.device);
   mmh_conv_meta m{meta.ishape.channels(), meta.ishape.height(), meta.ishape.width(), meta.fshape.height(),
                   meta.fshape.width(), (int64_t)meta.n_filters, meta.padding == Padding::SAME, (int32_t)meta.stride,
                   meta.is_shared_input};
@@ -283,40 +383,52 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
   TensorShape out_shape({oshape[0], oshape[1], oshape[2]});
   if (!out_tensor.shape().IsSameSize(out_shape)) out_tensor.Reshape(out_shape);
   const size_t img_words = (size_t)meta.ishape.num_elements(), out_words = (size_t)out_shape.num_elements();
-  Dev img(img_words);
-  img.upload(in_tensor.data(), img_words);
-  if (party_ == kBob) {
-    Dev a = I.uniform(I.ring.ctx, 0, n_in), e = I.noise(n_in), cts(n_in * 2 * L * N);
-    must(mmh_conv_encrypt_image(plan, I.ring.sk.p, img.p, a.p, (const int64_t *)e.p, cts.p, nullptr),
-         "CheetahLinear::conv2d encryptImage");
-    I.send_cts(cts, n_in, 2 * L * N);
-    Dev res = I.recv_cts(n_out, 2 * N), out(out_words);
-    must(mmh_conv_decrypt(plan, I.ring.sk_last.p, res.p, out.p, nullptr), "CheetahLinear::conv2d decryptToTensor");
-    out.download(out_tensor.data(), out_words);
-  } else {
+  Dev img = I.mk(img_words), out = I.mk(out_words), dfilt;
+  I.up(img, in_tensor.data(), img_words);
+  if (party_ == kAlice) {
     const size_t f_words = (size_t)meta.fshape.num_elements();
-    std::vector<uint64_t> fh(meta.n_filters * f_words);
-    for (size_t k = 0; k < filters.size(); ++k) std::copy(filters[k].data(), filters[k].data() + f_words, fh.begin() + k * f_words);
-    // conv2DOneFilter (hom_conv2d_ss.cc:573-580): an all-zero filter is an error (values are mod base_mod)
-    for (size_t k = 0; k < filters.size(); ++k) {
-      bool nz = false;
-      for (size_t i = 0; i < f_words && !nz; ++i) nz = (fh[k * f_words + i] % base_mod_) != 0;
-      if (!nz) throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
-    }
-    Dev dfilt(fh.size());
-    dfilt.upload(fh.data(), fh.size());
-    Dev cts = I.recv_cts(n_in, 2 * L * N);
-    Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
-    Dev out_cts(n_out * 2 * N), share(out_words);
-    // encodeImage + encodeFilters + conv2DSS (cheetah-api.cpp:401-445) in one device call; the zero-filter rule
-    // was settled on the host copy above
-    must(mmh_conv_server_tensors(plan, cts.p, meta.is_shared_input ? img.p : nullptr, dfilt.p, I.ring.pk_last.p,
-                                 (const int64_t *)u.p, (const int64_t *)e1.p, mask.p, out_cts.p, share.p, nullptr,
-                                 nullptr),
-         "CheetahLinear::conv2d conv2DSS:");
-    share.download(out_tensor.data(), out_words);
-    I.send_cts(out_cts, n_out, 2 * N);
+    dfilt = I.mk(meta.n_filters * f_words);
+    for (size_t k = 0; k < filters.size(); ++k)
+      must(mmh_memcpy_h2d(dfilt.p + k * f_words, filters[k].data(), f_words * 8, I.stream), "h2d");
   }
+  I.conv_core(party_, meta, plan, n_in, n_out, img, &dfilt, out, [&] { I.down(out_tensor.data(), out, out_words); });
+}
+
+// Conv2DWrapper's work (library_fixed_uniform_cheetah.cpp:216-300) without the host-side repacking: the NHWC input,
+// the [FH][FW][CI][CO] filters and the NHWC output cross the link as they are and change layout on the device.
+void CheetahLinear::conv2d_nhwc(const uint64_t *input_nhwc, const uint64_t *filters_hwio, const ConvMeta &meta,
+                                uint64_t *out_nhwc, int64_t expect_oh, int64_t expect_ow) const {
+  if (!input_nhwc || !out_nhwc || (party_ == kAlice && !filters_hwio))
+    throw std::invalid_argument("CheetahLinear::conv2d_nhwc null array");
+  const Impl &I = *impl_;
+  DeviceGuard dg(I.device);
+  const size_t C = (size_t)meta.ishape.channels(), H = (size_t)meta.ishape.height(), W = (size_t)meta.ishape.width();
+  const size_t fh = (size_t)meta.fshape.height(), fw = (size_t)meta.fshape.width(), M = meta.n_filters;
+  mmh_conv_meta m{(int64_t)C, (int64_t)H, (int64_t)W, (int64_t)fh, (int64_t)fw, (int64_t)M,
+                  meta.padding == Padding::SAME, (int32_t)meta.stride, meta.is_shared_input};
+  mmh_conv_plan *plan = I.conv_plan(m);
+  size_t n_in, n_cs, n_sp, n_out;
+  int64_t oshape[3];
+  must(mmh_conv_plan_info(plan, &n_in, &n_cs, &n_sp, &n_out, oshape, nullptr), "plan_info");
+  if ((expect_oh && expect_oh != oshape[1]) || (expect_ow && expect_ow != oshape[2]))
+    throw std::runtime_error("Conv2DWrapper: output shape differs from the caller's (pads / stride)");
+  const size_t img_words = C * H * W, out_words = (size_t)(oshape[0] * oshape[1] * oshape[2]);
+  const uint64_t ring_mask = base_mod_ - 1;  // getRingElt
+  Dev raw = I.mk(img_words), img = I.mk(img_words), out = I.mk(out_words), out_t = I.mk(out_words), dfilt;
+  I.up(raw, input_nhwc, img_words);
+  must(mmh_repack_nhwc_to_chw(raw.p, H, W, C, ring_mask, img.p, I.stream), "repack input");
+  if (party_ == kAlice) {
+    const size_t f_words = fh * fw * C * M;
+    Dev fraw = I.mk(f_words);
+    dfilt = I.mk(f_words);
+    I.up(fraw, filters_hwio, f_words);
+    must(mmh_repack_hwio_to_oihw(fraw.p, fh, fw, C, M, ring_mask, dfilt.p, I.stream), "repack filters");
+  }
+  I.conv_core(party_, meta, plan, n_in, n_out, img, &dfilt, out, [&] {
+    must(mmh_repack_chw_to_nhwc(out.p, (size_t)oshape[0], (size_t)oshape[1], (size_t)oshape[2], out_t.p, I.stream),
+         "repack output");
+    I.down(out_nhwc, out_t, out_words);
+  });
 }
 
 void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
@@ -327,50 +439,65 @@ void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64
   TensorShape out_shape({meta.weight_shape.dim_size(0)});
   if (!out_vec_share.shape().IsSameSize(out_shape)) out_vec_share.Reshape(out_shape);
   const Impl &I = *impl_;
+  DeviceGuard dg(I.device);
   const size_t N = Impl::N, L = Impl::L;
   mmh_fc_meta m{meta.weight_shape.rows(), meta.weight_shape.cols(), meta.is_shared_input};
   mmh_fc_plan *plan = I.fc_plan(m);
   size_t n_in, n_out;
   must(mmh_fc_plan_info(plan, nullptr, &n_in, &n_out), "plan_info");
   const size_t rows = (size_t)m.rows, cols = (size_t)m.cols;
-  Dev vec(cols);
-  vec.upload(input_vector.data(), cols);
+  Dev vec = I.mk(cols);
+  I.up(vec, input_vector.data(), cols);
   if (party_ == kBob) {
-    Dev a = I.uniform(I.ring.ctx, 0, n_in), e = I.noise(n_in), cts(n_in * 2 * L * N);
-    must(mmh_fc_encrypt_input(plan, I.ring.sk.p, vec.p, a.p, (const int64_t *)e.p, cts.p, nullptr),
+    Dev a = I.uniform(I.ring.ctx, 0, n_in), e = I.noise(n_in), cts = I.mk(n_in * 2 * L * N);
+    must(mmh_fc_encrypt_input(plan, I.ring.sk.p, vec.p, a.p, (const int64_t *)e.p, cts.p, I.stream),
          "CheetahLinear::fc encryptInputVector");
-    I.send_cts(cts, n_in, 2 * L * N);
-    Dev res = I.recv_cts(n_out, 2 * N), out(rows);
-    must(mmh_fc_decrypt(plan, I.ring.sk_last.p, res.p, out.p, nullptr), "CheetahLinear::fc decryptToVector");
-    out.download(out_vec_share.data(), rows);
+    I.stage_cts(cts, n_in * 2 * L * N);
+    I.sync();
+    I.send_staged(n_in, 2 * L * N);
+    Dev res = I.recv_cts(n_out, 2 * N), out = I.mk(rows);
+    must(mmh_fc_decrypt(plan, I.ring.sk_last.p, res.p, out.p, I.stream), "CheetahLinear::fc decryptToVector");
+    I.down(out_vec_share.data(), out, rows);
+    I.sync();
   } else {
-    Dev w(rows * cols), wpts(n_out * n_in * N), spts;
-    w.upload(weight_matrix.data(), rows * cols);
-    must(mmh_fc_encode_weights(plan, w.p, wpts.p, nullptr), "CheetahLinear::fc encodeWeightMatrix error");
-    {  // matVecMul rejects a sub-matrix that encodes to zero (hom_fc_ss.cc:414-422)
+    Dev w = I.mk(rows * cols), wpts = I.mk(n_out * n_in * N), spts;
+    I.up(w, weight_matrix.data(), rows * cols);
+    must(mmh_fc_encode_weights(plan, w.p, wpts.p, I.stream), "CheetahLinear::fc encodeWeightMatrix error");
+    {  // matVecMul rejects a sub-matrix that encodes to zero (hom_fc_ss.cc:414-422); base_mod is a power of two (ctor)
       int64_t split[2];
       must(mmh_fc_plan_info(plan, split, nullptr, nullptr), "plan_info");
-      for (size_t rb = 0; rb < n_out; ++rb)
+      const uint64_t ring_mask = base_mod_ - 1;
+      std::vector<uint8_t> nz(n_out * n_in, 0);
+      const uint64_t *wd = weight_matrix.data();
+      for (size_t r = 0; r < rows; ++r) {
+        uint8_t *row_nz = nz.data() + (r / (size_t)split[0]) * n_in;
         for (size_t cb = 0; cb < n_in; ++cb) {
-          bool nz = false;
-          for (size_t r = rb * split[0]; r < std::min<size_t>((rb + 1) * split[0], rows) && !nz; ++r)
-            for (size_t c = cb * split[1]; c < std::min<size_t>((cb + 1) * split[1], cols) && !nz; ++c)
-              nz = (weight_matrix.data()[r * cols + c] % base_mod_) != 0;
-          if (!nz) throw std::runtime_error("CheetahLinear::fc matmul2D error [" + CodeMessage(Code::ERR_INVALID_ARG) + "]");
+          if (row_nz[cb]) continue;
+          const size_t c1 = std::min<size_t>((cb + 1) * split[1], cols);
+          for (size_t c = cb * split[1]; c < c1; ++c)
+            if (wd[r * cols + c] & ring_mask) {
+              row_nz[cb] = 1;
+              break;
+            }
         }
+      }
+      for (uint8_t v : nz)
+        if (!v) throw std::runtime_error("CheetahLinear::fc matmul2D error [" + CodeMessage(Code::ERR_INVALID_ARG) + "]");
     }
     if (meta.is_shared_input) {
-      spts.alloc(n_in * N);
-      must(mmh_fc_encode_input(plan, vec.p, spts.p, nullptr), "CheetahLinear::fc encodeInputVector error");
+      spts = I.mk(n_in * N);
+      must(mmh_fc_encode_input(plan, vec.p, spts.p, I.stream), "CheetahLinear::fc encodeInputVector error");
     }
-    Dev cts = I.recv_cts(n_in, 2 * L * N);
     Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
-    Dev out_cts(n_out * 2 * N), share(rows);
+    Dev out_cts = I.mk(n_out * 2 * N), share = I.mk(rows);
+    Dev cts = I.recv_cts(n_in, 2 * L * N);
     must(mmh_fc_server(plan, cts.p, spts.p, wpts.p, I.ring.pk_last.p, (const int64_t *)u.p, (const int64_t *)e1.p, mask.p,
-                       out_cts.p, share.p, nullptr),
+                       out_cts.p, share.p, I.stream),
          "CheetahLinear::fc matmul2D error");
-    share.download(out_vec_share.data(), rows);
-    I.send_cts(out_cts, n_out, 2 * N);
+    I.down(out_vec_share.data(), share, rows);
+    I.stage_cts(out_cts, n_out * 2 * N);
+    I.sync();
+    I.send_staged(n_out, 2 * N);
   }
 }
 
@@ -381,33 +508,40 @@ void CheetahLinear::bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64
   if (meta.target_base_mod != field_mod_)
     throw std::runtime_error("bn encryptVector [" + CodeMessage(Code::ERR_OUT_BOUND) + "]");  // hom_bn_ss.cc:156
   const Impl &I = *impl_;
+  DeviceGuard dg(I.device);
   const size_t N = Impl::N, L = Impl::L, n = (size_t)meta.vec_shape.length();
   const size_t n_ct = (n + std::min(n, N) - 1) / std::min(n, N);
   if (!out_vector.shape().IsSameSize(meta.vec_shape)) out_vector.Reshape(meta.vec_shape);
   if (party_ == kBob) {
-    Dev vec(n), a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct), cts(n_ct * 2 * L * N);
-    vec.upload(input_vector.data(), n);
-    must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, vec.p, n, a.p, (const int64_t *)e.p, cts.p, nullptr),
+    Dev vec = I.mk(n), a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct), cts = I.mk(n_ct * 2 * L * N);
+    I.up(vec, input_vector.data(), n);
+    must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, vec.p, n, a.p, (const int64_t *)e.p, cts.p, I.stream),
          "bn encryptVector");
-    I.send_cts(cts, n_ct, 2 * L * N);
-    Dev res = I.recv_cts(n_ct, 2 * N), out(n);
-    must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, nullptr), "bn decryptToVector");
-    out.download(out_vector.data(), n);
+    I.stage_cts(cts, n_ct * 2 * L * N);
+    I.sync();
+    I.send_staged(n_ct, 2 * L * N);
+    Dev res = I.recv_cts(n_ct, 2 * N), out = I.mk(n);
+    must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, I.stream), "bn decryptToVector");
+    I.down(out_vector.data(), out, n);
+    I.sync();
   } else {
     if (!scale_vector.shape().IsSameSize(meta.vec_shape)) throw std::runtime_error("bn scale_vector shape mismatch");
-    Dev scale(n), sc_pts(n_ct * N), in_pts;
-    scale.upload(scale_vector.data(), n);
-    must(mmh_bn_encode_vector(I.field.ctx, scale.p, n, sc_pts.p, nullptr), "bn encodeScales");
+    Dev scale = I.mk(n), sc_pts = I.mk(n_ct * N), in_pts;
+    I.up(scale, scale_vector.data(), n);
+    must(mmh_bn_encode_vector(I.field.ctx, scale.p, n, sc_pts.p, I.stream), "bn encodeScales");
     if (meta.is_shared_input) {
-      Dev vec(n);
-      vec.upload(input_vector.data(), n);
-      in_pts.alloc(n_ct * N);
-      must(mmh_bn_encode_vector(I.field.ctx, vec.p, n, in_pts.p, nullptr), "bn encodeVector");
+      Dev vec = I.mk(n);
+      I.up(vec, input_vector.data(), n);
+      in_pts = I.mk(n_ct * N);
+      must(mmh_bn_encode_vector(I.field.ctx, vec.p, n, in_pts.p, I.stream), "bn encodeVector");
     }
-    Dev cts = I.recv_cts(n_ct, 2 * L * N), rnd = I.words(n), out_cts(n_ct * 2 * N), share(n);
-    must(mmh_bn_server(I.field.ctx, cts.p, in_pts.p, sc_pts.p, n, rnd.p, out_cts.p, share.p, nullptr), "bn failed");
-    share.download(out_vector.data(), n);
-    I.send_cts(out_cts, n_ct, 2 * N);
+    Dev rnd = I.words(n), out_cts = I.mk(n_ct * 2 * N), share = I.mk(n);
+    Dev cts = I.recv_cts(n_ct, 2 * L * N);
+    must(mmh_bn_server(I.field.ctx, cts.p, in_pts.p, sc_pts.p, n, rnd.p, out_cts.p, share.p, I.stream), "bn failed");
+    I.down(out_vector.data(), share, n);
+    I.stage_cts(out_cts, n_ct * 2 * N);
+    I.sync();
+    I.send_staged(n_ct, 2 * N);
   }
 }
 
@@ -418,6 +552,7 @@ void CheetahLinear::bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor
     throw std::runtime_error("bn_direct input_vector shape mismatch");
   if (meta.ishape.dims() != 3) throw std::runtime_error("bn_direct encryptVector [" + CodeMessage(Code::ERR_CONFIG) + "]");
   const Impl &I = *impl_;
+  DeviceGuard dg(I.device);
   const size_t N = Impl::N, L = Impl::L;
   mmh_bn_tensor_meta m{meta.ishape.channels(), meta.ishape.height(), meta.ishape.width(), meta.is_shared_input};
   size_t n_ct = 0;
@@ -427,33 +562,38 @@ void CheetahLinear::bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor
   if (party_ == kBob) {
     if (!input_tensor.shape().IsSameSize(meta.ishape))
       throw std::runtime_error("bn_direct encryptVector [" + CodeMessage(Code::ERR_CONFIG) + "]");  // hom_bn_ss.cc:527
-    Dev x(words), a = I.uniform(I.ring.ctx, 0, n_ct), e = I.noise(n_ct), cts(n_ct * 2 * L * N);
-    x.upload(input_tensor.data(), words);
-    must(mmh_bn_encrypt_tensor(I.ring.ctx, &m, I.ring.sk.p, x.p, a.p, (const int64_t *)e.p, cts.p, nullptr),
+    Dev x = I.mk(words), a = I.uniform(I.ring.ctx, 0, n_ct), e = I.noise(n_ct), cts = I.mk(n_ct * 2 * L * N);
+    I.up(x, input_tensor.data(), words);
+    must(mmh_bn_encrypt_tensor(I.ring.ctx, &m, I.ring.sk.p, x.p, a.p, (const int64_t *)e.p, cts.p, I.stream),
          "bn_direct encryptVector");
-    I.send_cts(cts, n_ct, 2 * L * N);
-    Dev res = I.recv_cts(n_ct, 2 * N), out(words);
-    must(mmh_bn_decrypt_tensor(I.ring.ctx, &m, I.ring.sk_last.p, res.p, out.p, nullptr), "bn_direct decryptToTensor");
-    out.download(out_tensor.data(), words);
+    I.stage_cts(cts, n_ct * 2 * L * N);
+    I.sync();
+    I.send_staged(n_ct, 2 * L * N);
+    Dev res = I.recv_cts(n_ct, 2 * N), out = I.mk(words);
+    must(mmh_bn_decrypt_tensor(I.ring.ctx, &m, I.ring.sk_last.p, res.p, out.p, I.stream), "bn_direct decryptToTensor");
+    I.down(out_tensor.data(), out, words);
+    I.sync();
   } else {
     if (scale_vector.dims() != 1 || scale_vector.length() != input_tensor.channels())
       throw std::runtime_error("bn_direct scale_vector shape mismatch");
-    Dev scales((size_t)scale_vector.length()), in_pts;
-    scales.upload(scale_vector.data(), (size_t)scale_vector.length());
+    Dev scales = I.mk((size_t)scale_vector.length()), in_pts;
+    I.up(scales, scale_vector.data(), (size_t)scale_vector.length());
     if (meta.is_shared_input) {
-      Dev x(words);
-      x.upload(input_tensor.data(), words);
-      in_pts.alloc(n_ct * N);
-      must(mmh_bn_encode_tensor(I.ring.ctx, &m, x.p, in_pts.p, nullptr), "bn_direct encodeVector");
+      Dev x = I.mk(words);
+      I.up(x, input_tensor.data(), words);
+      in_pts = I.mk(n_ct * N);
+      must(mmh_bn_encode_tensor(I.ring.ctx, &m, x.p, in_pts.p, I.stream), "bn_direct encodeVector");
     }
+    Dev u = I.ternary(n_ct), e0 = I.noise(n_ct), e1 = I.noise(n_ct), share1 = I.words(words), out_cts = I.mk(n_ct * 2 * N);
     Dev cts = I.recv_cts(n_ct, 2 * L * N);
-    Dev u = I.ternary(n_ct), e0 = I.noise(n_ct), e1 = I.noise(n_ct), share1 = I.words(words), out_cts(n_ct * 2 * N);
     must(mmh_bn_direct_server(I.ring.ctx, &m, cts.p, in_pts.p, scales.p, I.ring.pk.p, (const int64_t *)u.p,
-                              (const int64_t *)e0.p, (const int64_t *)e1.p, share1.p, out_cts.p, nullptr),
+                              (const int64_t *)e0.p, (const int64_t *)e1.p, share1.p, out_cts.p, I.stream),
          "bn_direct failed");
-    share1.download(out_tensor.data(), words);  // hom_bn_ss.cc:712-723: the random tensor, reduced mod base_mod
+    I.down(out_tensor.data(), share1, words);  // hom_bn_ss.cc:712-723: the random tensor, reduced mod base_mod
+    I.stage_cts(out_cts, n_ct * 2 * N);
+    I.sync();
     for (size_t i = 0; i < words; ++i) out_tensor.data()[i] &= base_mod_ - 1;
-    I.send_cts(out_cts, n_ct, 2 * N);
+    I.send_staged(n_ct, 2 * N);
   }
 }
 
@@ -463,34 +603,43 @@ void CheetahLinear::BOLE(const Tensor<uint64_t> &x, const Tensor<uint64_t> &y, c
     throw std::runtime_error("BOLE input_vector shape mismatch");
   if (meta.target_base_mod != field_mod_) throw std::runtime_error("BOLE [" + CodeMessage(Code::ERR_OUT_BOUND) + "]");
   const Impl &I = *impl_;
+  DeviceGuard dg(I.device);
   const size_t N = Impl::N, L = Impl::L, n = (size_t)meta.vec_shape.length();
   const size_t n_ct = (n + std::min(n, N) - 1) / std::min(n, N), ct_words = 2 * L * N;
   if (!out_vector.shape().IsSameSize(meta.vec_shape)) out_vector.Reshape(meta.vec_shape);
-  Dev dx(n), dy(n), out(n);
-  dx.upload(x.data(), n);
-  dy.upload(y.data(), n);
+  Dev dx = I.mk(n), dy = I.mk(n), out = I.mk(n);
+  I.up(dx, x.data(), n);
+  I.up(dy, y.data(), n);
   if (party_ == kBob) {
-    Dev cts(2 * n_ct * ct_words);
+    Dev cts = I.mk(2 * n_ct * ct_words);
     for (int k = 0; k < 2; ++k) {  // encryptVector(x), encryptVector(y)  (cheetah-api.cpp:617-621)
       Dev a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct);
       must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, k ? dy.p : dx.p, n, a.p, (const int64_t *)e.p,
-                                 cts.p + k * n_ct * ct_words, nullptr),
+                                 cts.p + k * n_ct * ct_words, I.stream),
            "BOLE encryptVector");
     }
-    I.send_cts(cts, 2 * n_ct, ct_words);
+    I.stage_cts(cts, 2 * n_ct * ct_words);
+    I.sync();
+    I.send_staged(2 * n_ct, ct_words);
     Dev res = I.recv_cts(n_ct, 2 * N);
-    must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, nullptr), "BOLE decryptToVector");
+    must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, I.stream), "BOLE decryptToVector");
+    // local cross term x_i * y_i (cheetah-api.cpp:648-649)
+    must(mmh_bole_cross_term(out.p, dx.p, dy.p, n, field_mod_, I.stream), "BOLE cross term");
+    I.down(out_vector.data(), out, n);
+    I.sync();
   } else {
-    Dev pts(2 * n_ct * N);  // [py ; px]
-    must(mmh_bn_encode_vector(I.field.ctx, dy.p, n, pts.p, nullptr), "BOLE encodeVector");
-    must(mmh_bn_encode_vector(I.field.ctx, dx.p, n, pts.p + n_ct * N, nullptr), "BOLE encodeVector");
-    Dev cts = I.recv_cts(2 * n_ct, ct_words), rnd = I.words(n), out_cts(n_ct * 2 * N);
-    must(mmh_bole_server(I.field.ctx, cts.p, pts.p, n, rnd.p, out_cts.p, out.p, nullptr), "BOLE bole");
-    I.send_cts(out_cts, n_ct, 2 * N);
+    Dev pts = I.mk(2 * n_ct * N);  // [py ; px]
+    must(mmh_bn_encode_vector(I.field.ctx, dy.p, n, pts.p, I.stream), "BOLE encodeVector");
+    must(mmh_bn_encode_vector(I.field.ctx, dx.p, n, pts.p + n_ct * N, I.stream), "BOLE encodeVector");
+    Dev rnd = I.words(n), out_cts = I.mk(n_ct * 2 * N);
+    Dev cts = I.recv_cts(2 * n_ct, ct_words);
+    must(mmh_bole_server(I.field.ctx, cts.p, pts.p, n, rnd.p, out_cts.p, out.p, I.stream), "BOLE bole");
+    must(mmh_bole_cross_term(out.p, dx.p, dy.p, n, field_mod_, I.stream), "BOLE cross term");
+    I.down(out_vector.data(), out, n);
+    I.stage_cts(out_cts, n_ct * 2 * N);
+    I.sync();
+    I.send_staged(n_ct, 2 * N);
   }
-  // local cross term x_i * y_i on both sides (cheetah-api.cpp:648-649)
-  must(mmh_bole_cross_term(out.p, dx.p, dy.p, n, field_mod_, nullptr), "BOLE cross term");
-  out.download(out_vector.data(), n);
 }
 
 // cheetah-api.cpp:206-296.  Shares are combined mod base_mod; the cleartext convolution follows

@@ -72,29 +72,11 @@ void Library::Conv2DWrapper(signedIntType N, signedIntType H, signedIntType W, s
   meta.padding = (zPadHLeft + zPadHRight + zPadWLeft + zPadWRight) == 0 ? Padding::VALID : Padding::SAME;
   meta.stride = (size_t)strideH;
   meta.is_shared_input = kIsSharedInput;
-  std::vector<Tensor<intType>> filters((size_t)CO, Tensor<intType>(meta.fshape));
-  // [FH][FW][CI][CO] -> per filter [CI][FH][FW] (raw indexing: the element accessors check bounds on every call)
-  for (signedIntType p = 0; p < CO; ++p) {
-    intType *f = filters[(size_t)p].data();
-    for (signedIntType k = 0; k < CI; ++k)
-      for (signedIntType i = 0; i < FH; ++i)
-        for (signedIntType j = 0; j < FW; ++j)
-          f[(k * FH + i) * FW + j] = getRingElt(filterArr[((i * FW + j) * CI + k) * CO + p]);
-  }
-  for (signedIntType b = 0; b < N; ++b) {
-    Tensor<intType> image(meta.ishape), out_tensor;
-    intType *img = image.data();
-    for (signedIntType p = 0; p < CI; ++p)
-      for (signedIntType j = 0; j < H; ++j)
-        for (signedIntType k = 0; k < W; ++k) img[(p * H + j) * W + k] = getRingElt(inputArr[((b * H + j) * W + k) * CI + p]);
-    cheetah_linear->conv2d(image, filters, meta, out_tensor);
-    if (out_tensor.channels() != CO || out_tensor.height() != newH || out_tensor.width() != newW)
-      throw std::runtime_error("Conv2DWrapper: output shape differs from the caller's (pads / stride)");
-    const intType *o = out_tensor.data();
-    for (signedIntType j = 0; j < newH; ++j)
-      for (signedIntType k = 0; k < newW; ++k)
-        for (signedIntType p = 0; p < CO; ++p) outArr[((b * newH + j) * newW + k) * CO + p] = o[(p * newH + j) * newW + k];
-  }
+  // The reference repacks on the host, element by element ([FH][FW][CI][CO] -> per filter [CI][FH][FW] with
+  // getRingElt :236-262, [H][W][CI] -> [CI][H][W] :284-287, the result back :293-299); here the arrays cross the link
+  // as they are and change layout on the device (CheetahLinear::conv2d_nhwc).  Same values either way.
+  for (signedIntType b = 0; b < N; ++b)
+    cheetah_linear->conv2d_nhwc(inputArr + b * H * W * CI, filterArr, meta, outArr + b * newH * newW * CO, newH, newW);
 }
 
 // :429-490: channel-wise scaling through bn_direct, then the bias share is added

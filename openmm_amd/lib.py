@@ -35,6 +35,13 @@ SIGNATURES = {
     "mmh_free": [_vp],
     "mmh_host_alloc": [C.POINTER(_vp), _sz],
     "mmh_host_free": [_vp],
+    "mmh_get_device": [C.POINTER(_int)],
+    "mmh_set_device": [_int],
+    "mmh_stream_create": [C.POINTER(_vp)],
+    "mmh_stream_destroy": [_vp],
+    "mmh_repack_nhwc_to_chw": [_vp, _sz, _sz, _sz, _u64, _vp, _vp],
+    "mmh_repack_chw_to_nhwc": [_vp, _sz, _sz, _sz, _vp, _vp],
+    "mmh_repack_hwio_to_oihw": [_vp, _sz, _sz, _sz, _sz, _u64, _vp, _vp],
     "mmh_host_register": [_vp, _sz],
     "mmh_host_unregister": [_vp],
     "mmh_scratch_release": [],
@@ -125,6 +132,8 @@ SIGNATURES = {
     "mmh_trunc_post": [_int, _vp, _vp, _sz, _int, _int, _int, _int, _vp, _vp],
     "mmh_trunc_reduce_pre": [_vp, _sz, _int, _vp, _vp],
     "mmh_trunc_reduce_post": [_vp, _vp, _sz, _int, _int, _vp, _vp],
+    "mmh_fused_bn_filters": [_vp, _vp, _int, _int, _int, _int, _int, _int, _u64, _int, _vp, _vp, _vp],
+    "mmh_fused_bn_bias": [_vp, _vp, _sz, _int, _int, _vp],
     "mmh_bole_cross_term": [_vp, _vp, _vp, _sz, _u64, _vp],
     "mmh_cot_wire_bytes": [_sz, _int, _u64, _int, C.POINTER(_sz)],
     "mmh_cot_gids": [_sz, C.POINTER(_u64)],

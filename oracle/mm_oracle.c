@@ -665,6 +665,42 @@ void mmo_r2r128_post(int party, const uint64_t *tmp, const uint8_t *msb, const u
   }
 }
 
+/* ---- FusedBN filter scaling, networks/main_resnet50.cpp:1728-1766 (server branch), with getSignValue :21-28 and
+ * sci::neg_mod (SCI/src/utils/utils.hpp:229-231).  filters and out are [fh][fw][ci][co] (Arr4DIdxRowM), scales [co].
+ * The only floating point on the path: double arithmetic and std::round exactly as written.  Returns 1 when every
+ * scaled filter entry is zero (the reference then prints a warning and exits, :1754-1762), else 0. */
+#include <math.h>
+static int64_t get_sign_value(uint64_t x, int bitlength) {           /* :21-28 */
+  int64_t upper = (int64_t)1 << bitlength;
+  uint64_t mask = (uint64_t)upper - 1, half = (uint64_t)upper >> 1;
+  x &= mask;
+  return (int64_t)(x >= half ? x - (uint64_t)upper : x);
+}
+static int64_t neg_mod_i64(int64_t val, int64_t mod) { return ((val % mod) + mod) % mod; }
+int mmo_fused_bn_filters(const uint64_t *filters, const uint64_t *bn_scales, long fh, long fw, long ci, long co,
+                         int bitlength, int k_scale, uint64_t prime_mod, uint64_t *out) {
+  const double scale = pow(2., k_scale);                             /* :1736 */
+  int all_zero = 1;
+  for (long h = 0; h < fh; h++)
+    for (long w = 0; w < fw; w++)
+      for (long c = 0; c < ci; c++)
+        for (long m = 0; m < co; m++) {
+          const double bn_scale = get_sign_value(bn_scales[m], bitlength) / scale;          /* :1741 */
+          const size_t idx = (size_t)((h * fw + w) * ci + c) * (size_t)co + (size_t)m;
+          const double fval = get_sign_value(filters[idx], bitlength) / scale;             /* :1747 */
+          const int64_t f64 = (int64_t)round(fval * bn_scale * scale);                      /* :1748 */
+          out[idx] = (uint64_t)neg_mod_i64(f64, (int64_t)prime_mod);                        /* :1749 */
+          if (out[idx]) all_zero = 0;
+        }
+  return all_zero;
+}
+/* the bias the server adds after the convolution, :1771-1786: ScaleUp1 (arr << sf in the SCI_OT build,
+ * library_fixed_uniform.cpp:1394-1402) then SecretAdd = plain wrapping add (:1861-1867), NHWC output */
+void mmo_fused_bn_bias(uint64_t *out_nhwc, const uint64_t *bn_bias, size_t pixels, size_t co, int k_scale) {
+  for (size_t p = 0; p < pixels; p++)
+    for (size_t m = 0; m < co; m++) out_nhwc[p * co + m] += bn_bias[m] << k_scale;
+}
+
 /* ---- Truncation::truncate / truncate_msb / truncate_msb0 of the USE_CHEETAH build (truncation-cheetah.cpp) and
  * truncate_and_reduce (truncation.cpp:289-317): the local share arithmetic around their wrap / B2A sub-protocols.
  * pre: the msb0 heuristic's +2^(bw-3) on BOB (truncation-cheetah.cpp:23-29), the signed case's +2^(bw-1) on ALICE

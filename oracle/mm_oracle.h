@@ -188,6 +188,11 @@ void mmo_ideal_cot(const uint64_t *x, const uint64_t *corr, const uint8_t *b, si
 uint64_t mmo_modulo_mult(uint64_t a, uint64_t b, uint64_t mod);
 void mmo_bole_cross_term(uint64_t *out, const uint64_t *x, const uint64_t *y, size_t n, uint64_t p);
 
+/* FusedBN (networks/main_resnet50.cpp:1728-1788): filter scaling in double arithmetic + round, and the bias add */
+int mmo_fused_bn_filters(const uint64_t *filters, const uint64_t *bn_scales, long fh, long fw, long ci, long co,
+                         int bitlength, int k_scale, uint64_t prime_mod, uint64_t *out);
+void mmo_fused_bn_bias(uint64_t *out_nhwc, const uint64_t *bn_bias, size_t pixels, size_t co, int k_scale);
+
 /* ---- COT post-processing (mm_cot_oracle.c): SilentOT::send/recv_ot_cam_cc[_prime], silent_ot.h:85-242 ----
  * AES-128 per FIPS-197; MITCCRH<8> restated from emp-tool 44b1dde [upstream-recall, parity unpinned] */
 void mmo_aes128_expand(const uint8_t key[16], uint8_t rk[176]);

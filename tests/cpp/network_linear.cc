@@ -87,7 +87,13 @@ int main(int argc, char **argv) {
   });
 
   int layers = 0, failures = 0;
-  double total_ms = 0;
+  double total_ms = 0, cold_ms = 0;
+  uint64_t transport0 = 0, bytes0 = 0;
+  // pass 0 is the first inference after start-up (per shape: geometry tables, first device and page-locked
+  // allocations); pass 1 is what every later inference costs and is the figure reported
+  for (int pass = 0; pass < 2; ++pass) {
+  if (pass == 1) cold_ms = total_ms, total_ms = 0, layers = 0, transport0 = io[0]->transport_ns(), bytes0 = io[0]->counter + io[1]->counter;
+  rng.seed(0x4D264D);
   for (size_t k = 0; k < n_shapes; ++k) {
     const Shape &sh = net[k];
     const int oh = (sh.H + 2 * sh.pad - sh.fh) / sh.stride + 1, ow = (sh.W + 2 * sh.pad - sh.fw) / sh.stride + 1;
@@ -130,9 +136,11 @@ int main(int argc, char **argv) {
       ok = std::llabs(to_signed(out[0][o] + out[1][o], l) - acc) <= 1;
     }
     if (!ok) ++failures;
-    std::printf("%s conv %4dx%3dx%3d %dx%d -> %4d s%d x%d: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", sh.C, sh.H,
-                sh.W, sh.fh, sh.fw, sh.M, sh.stride, sh.count, ms);
+    if (pass == 1 || !ok)
+      std::printf("%s conv %4dx%3dx%3d %dx%d -> %4d s%d x%d: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", sh.C, sh.H,
+                  sh.W, sh.fh, sh.fw, sh.M, sh.stride, sh.count, ms);
     total_ms += ms;
+  }
   }
   if (resnet) {  // FC 2048 -> 1001 on the pooled features: MatMul2D(1, 2048, 1001, x, W, out, false)
     const int in = 2048, outn = 1001;
@@ -158,6 +166,9 @@ int main(int argc, char **argv) {
     std::printf("%s fc   2048 -> 1001 through MatMul2D: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", ms);
     total_ms += ms;
   }
+  std::printf("first inference after start-up: %.1f ms\n", cold_ms);
+  std::printf("in-process transport (the byte pipe's copies, the stand-in for the network): %.1f ms for %.1f MiB both ways\n",
+              (io[0]->transport_ns() - transport0) * 1e-6, (io[0]->counter + io[1]->counter - bytes0) / 1048576.0);
   std::printf("%s: %d convolutions through Conv2DWrapper, both parties in-process, %.1f ms in total (host tensors in,\n"
               "host tensors out, encryption, transport through a byte pipe and decryption included)\n",
               densenet ? "DenseNet121" : (resnet ? "ResNet50" : "SqueezeNet"), layers, total_ms);
