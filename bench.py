@@ -25,12 +25,16 @@ MADS_PER_BUTTERFLY = (9 + 8) / 2
 MAD_PEAK = 34.5e12         # lanes/s measured on MI355X (profiles/r01_a_valu_probe.txt, r01_f64_probe.txt)
 
 
+PMC_FILE = "profiles/r02_ntt_pmc.json"
+
+
 def pmc_traffic(ntts_per_launch):
-    """HBM bytes per launch of ntt_fwd_kernel<12> from the committed rocprofv3 --pmc passes
-    (tools/evidence.sh -> profiles/r01_ntt_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of
-    MI355X_MICROARCH.md), scaled from the 8192 limb-NTTs per launch they were collected on."""
+    """HBM bytes per launch of ntt_fwd_kernel<12>: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of
+    MI355X_MICROARCH.md) from separate rocprofv3 --pmc passes over the same kernel (tools/evidence.sh ->
+    profiles/r02_ntt_pmc.json, collected on 8192 limb-NTTs per launch), scaled to this launch.  PMC passes cannot run
+    inside this process, so the figure is the RECORDED one; `traffic_source` in the line names the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             return json.load(f)["traffic_bytes"] * ntts_per_launch / 8192
     except (OSError, KeyError, ValueError):
         return None
@@ -513,6 +517,7 @@ def main():
                        "parallelism": f"independent batches x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(ntts_per_step),
+                         "traffic_source": f"recorded, not measured in this run: {PMC_FILE} (tools/evidence.sh, round 2)",
                          "kernel": "ntt_fwd_kernel<12>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ntts_per_step * BYTES_PER_NTT[4096],
                          "int64_valu": {"achieved": ntts_per_step * BUTTERFLIES[4096] * MADS_PER_BUTTERFLY

@@ -94,6 +94,17 @@ int mmh_ntt_inverse(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_
 int mmh_ntt_forward_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, void *stream);
 int mmh_ntt_inverse_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, void *stream);
 
+/* the same transforms one limb at a time: every polynomial of the batch [n_polys][N] modulo q[limb_index], as the
+ * reference's own loops call them with ntt_tables[i] (hom_conv2d_ss.cc:306,315,333) */
+int mmh_ntt_forward_limb(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_t limb_index, void *stream);
+int mmh_ntt_inverse_limb(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_t limb_index, void *stream);
+/* seal::util polynomial arithmetic modulo one word-sized modulus (seal/util/polyarithsmallmod.h), element-wise on n
+ * coefficients: op 0 add_poly_coeffmod (hom_conv2d_ss.cc:335,375), 1 sub_poly_coeffmod (:99), 2 dyadic_product_coeffmod
+ * (:308), 3 multiply_poly_scalar_coeffmod by `scalar` (hom_bn_ss.cc:637), 4 modulo_poly_coeffs (hom_conv2d_ss.cc:264,
+ * tensor_encoder.cc:317).  d_b is unused for ops 3 and 4; d_out may alias an operand. */
+int mmh_poly_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t scalar, size_t n, uint64_t modulus,
+                uint64_t *d_out, void *stream);
+
 /* =====================================================================================
  * BFV arithmetic on batches of ciphertexts / plaintexts (BFV contexts only: t >= 2, L <= 2).
  * lv selects the level: 0 = first level (all L limbs), 1 = last level ({q0} only,

@@ -436,6 +436,24 @@ static int check_bfv(const mmh_ctx *ctx, int lv) {
   return MMH_OK;
 }
 static inline int limbs_of(const mmh_ctx *ctx, int lv) { return lv == 0 ? (int)ctx->L : 1; }
+// seal::util polynomial arithmetic modulo one word-sized modulus, element-wise (polyarithsmallmod.h as the
+// reference's loops use it): op 0 a + b, 1 a - b, 2 a * b (dyadic), 3 a * scalar, 4 a mod m.  Operands of the
+// first four are reduced (below m); op 4 takes any 64-bit value.
+__global__ __launch_bounds__(256) void poly_op_kernel(int op, const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                      u64 scalar, size_t n, ModC m, u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 x = a[i];
+  u64 r;
+  switch (op) {
+    case 0: r = add_mod(x, b[i], m.q); break;
+    case 1: r = sub_mod(x, b[i], m.q); break;
+    case 2: r = barrett128(mulhi64(x, b[i]), x * b[i], m.q, m.barrett_hi, m.barrett_lo); break;
+    case 3: r = barrett128(mulhi64(x, scalar), x * scalar, m.q, m.barrett_hi, m.barrett_lo); break;
+    default: r = barrett128(0, x, m.q, m.barrett_hi, m.barrett_lo); break;
+  }
+  out[i] = r;
+}
 }  // namespace mmh
 
 using namespace mmh;
@@ -821,5 +839,19 @@ extern "C" int mmh_batch_decode_noalloc(const mmh_ctx *ctx, const uint64_t *d_pt
   MMH_HIP(hipMemcpyAsync(tmp, d_pts, n * ctx->N * 8, hipMemcpyDeviceToDevice, s));
   CHECK_RC(ntt_dispatch(ctx, false, tmp, n, 1, (int)ctx->L, s));
   LAUNCH(slot_gather_kernel, n * ctx->N, s, tmp, d_vals, n * ctx->N, ctx->logN, ctx->d_slot_map);
+  return MMH_OK;
+}
+
+extern "C" int mmh_poly_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t scalar, size_t n,
+                           uint64_t modulus, uint64_t *d_out, void *stream) {
+  MMH_REQUIRE(op >= 0 && op <= 4, MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(modulus >= 2 && modulus < (uint64_t(1) << 62), MMH_ERR_INVALID_ARG);  // SEAL moduli are at most 61 bits
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_a && d_out && (d_b || op >= 3), MMH_ERR_NULL_POINTER);
+  const unsigned __int128 ratio =
+      (modulus & (modulus - 1)) ? ~(unsigned __int128)0 / modulus : (~(unsigned __int128)0 / modulus) + 1;
+  const ModC m{modulus, (u64)(ratio >> 64), (u64)ratio};
+  hipStream_t s = (hipStream_t)stream;
+  LAUNCH(poly_op_kernel, n, s, op, d_a, d_b, scalar, n, m, d_out);
   return MMH_OK;
 }

@@ -639,3 +639,20 @@ extern "C" int mmh_ntt_inverse_t(const mmh_ctx *ctx, uint64_t *d_polys, size_t n
   MMH_REQUIRE(ctx->batching, MMH_ERR_CONFIG);
   return ntt_dispatch(ctx, true, d_polys, n_polys, 1, (int)ctx->L, (hipStream_t)stream);
 }
+// one limb at a time, as the reference's own loops call seal::util::ntt_negacyclic_harvey[_lazy] /
+// inverse_ntt_negacyclic_harvey with ntt_tables[i] (hom_conv2d_ss.cc:306,315,333): every polynomial of the batch is
+// transformed modulo q[limb_index]
+extern "C" int mmh_ntt_forward_limb(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_t limb_index,
+                                    void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  MMH_REQUIRE(ctx && (d_polys || n_polys == 0), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(limb_index < ctx->L, MMH_ERR_DIM_MISMATCH);
+  return ntt_dispatch(ctx, false, d_polys, n_polys, 1, (int)limb_index, (hipStream_t)stream);
+}
+extern "C" int mmh_ntt_inverse_limb(const mmh_ctx *ctx, uint64_t *d_polys, size_t n_polys, size_t limb_index,
+                                    void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  MMH_REQUIRE(ctx && (d_polys || n_polys == 0), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(limb_index < ctx->L, MMH_ERR_DIM_MISMATCH);
+  return ntt_dispatch(ctx, true, d_polys, n_polys, 1, (int)limb_index, (hipStream_t)stream);
+}

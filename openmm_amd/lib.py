@@ -53,6 +53,9 @@ SIGNATURES = {
     "mmh_ntt_inverse": [_vp, _vp, _sz, _sz, _vp],
     "mmh_ntt_forward_t": [_vp, _vp, _sz, _vp],
     "mmh_ntt_inverse_t": [_vp, _vp, _sz, _vp],
+    "mmh_ntt_forward_limb": [_vp, _vp, _sz, _sz, _vp],
+    "mmh_ntt_inverse_limb": [_vp, _vp, _sz, _sz, _vp],
+    "mmh_poly_op": [_int, _vp, _vp, _u64, _sz, _u64, _vp, _vp],
     "mmh_add_plain": [_vp, _int, _vp, _vp, _sz, _int, _vp, _vp],
     "mmh_plain_lift_ntt": [_vp, _int, _vp, _sz, _vp, _vp],
     "mmh_dyadic_mac": [_vp, _int, _vp, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _vp],
