@@ -269,7 +269,7 @@ def densenet121_convs():
 
 
 def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None, prefix="resnet50", with_fc=True,
-                 all_modes=True):
+                 all_modes=True, prepared=True):
     """Second half of BASELINE.json's metric: server-side HE compute of all 53 ResNet50 conv layers
     + FC 2048->1001 (what CheetahLinear::conv2d / ::fc run between receiving the client's
     ciphertexts and sending the result, cheetah-api.cpp:417-445, :520-548): filter encoding and
@@ -316,7 +316,9 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
         def layer():   # encodeImage + encodeFilters + conv2DSS in one device call
             return srv.conv2DSSFromTensors(cts, share if shared else None, filters, meta, rand)
 
-        if world == 1:
+        if world == 1 and not prepared:
+            ms = wall_ms(layer)
+        elif world == 1:
             ms = wall_ms(layer)
             # static weights prepared once per model (not what the reference does: reported apart)
             prep = srv.prepareFilters(filters, meta)

@@ -12,6 +12,10 @@ int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys,
                  int mod_base, hipStream_t s);
 int ntt_signed_dispatch(const mmh_ctx *ctx, const int64_t *d_src, u64 *d_out, size_t n_polys, int limbs,
                         hipStream_t s);
+int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, size_t n, const u64 *d_acc,
+                            const int64_t *d_e1, const u64 *d_mask, u64 *d_out, const uint8_t *d_keep,
+                            size_t keep_period, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
+                            hipStream_t s);
 int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, u64 *d_out, size_t n,
                              int limbs, hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
@@ -341,74 +345,6 @@ __global__ __launch_bounds__(256) void truncate_kernel(u64 *__restrict__ cts, si
   u64 *c0 = cts + ((k * 2) << logN) + i, *c1 = c0 + (size_t(1) << logN);
   *c0 = kept ? (*c0 & mask0) : 0;  // remove_unused_coeffs walks ct.data(0) only: c1 keeps every coefficient
   *c1 &= mask1;
-}
-
-// Re-sharing tail of the approximate build, one pass per output ciphertext (hom_conv2d_ss.cc:761-788,
-// :392-441, :108-140): out = truncate(mod_switch(acc) + zero + (0, e1) - (mask, 0)) with the unused
-// coefficients of c0 cleared.  acc [n][2][2][N] coefficient form at the first level; zero [n][2][N] the
-// noiseless pk-encryption of zero at the last level; mask [n][N] mod q0; e1 signed.
-// Two neighbouring coefficients per thread: 16-byte loads and stores on every stream.
-__global__ __launch_bounds__(256) void reshare_finish_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ zero,
-                                                             const int64_t *__restrict__ e1,
-                                                             const u64 *__restrict__ mask, u64 *__restrict__ out,
-                                                             size_t total, int logN, u64 inv_qlast, u64 mask0,
-                                                             u64 mask1, const uint8_t *__restrict__ keep,
-                                                             size_t keep_period, const DevMod *__restrict__ mods,
-                                                             const int *__restrict__ share_dst, size_t share_plane,
-                                                             u64 *__restrict__ share_out, BfvConsts b) {
-  const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;  // over [n][N], an even coefficient
-  if (idx >= total) return;
-  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
-  const DevMod &q0 = mods[0];
-  typedef ulonglong2 v2;
-  auto ld2 = [](const u64 *ptr) { return *reinterpret_cast<const v2 *>(ptr); };
-  const size_t kp = ((k % keep_period) << logN) + i;
-  bool kept[2] = {true, true};
-  if (keep) {
-    const uchar2 kk = *reinterpret_cast<const uchar2 *>(keep + kp);
-    kept[0] = kk.x != 0, kept[1] = kk.y != 0;
-  }
-  const bool any_kept = kept[0] || kept[1];
-  v2 m = {0, 0};
-  if (any_kept || share_dst) m = ld2(mask + idx);
-  if (share_dst) {  // the other party's share: scale-and-round of the mask at the target coefficients
-    const int2 dst = *reinterpret_cast<const int2 *>(share_dst + kp);
-    if (dst.x >= 0) {
-      const u64 x[2] = {m.x, 0};
-      share_out[(k / keep_period) * share_plane + dst.x] = behz_round(x, b, b.lv[1], mods);
-    }
-    if (dst.y >= 0) {
-      const u64 x[2] = {m.y, 0};
-      share_out[(k / keep_period) * share_plane + dst.y] = behz_round(x, b, b.lv[1], mods);
-    }
-  }
-  const u64 q1 = mods[1].q, half = q1 >> 1, half0 = reduce64(half, q0);
-  auto switched = [&](u64 a0, u64 a1, u64 z) {  // divide_and_round_q_last, then the encryption of zero
-    const u64 last = csub(a1 + half, q1);
-    const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
-    return add_mod(mul_mod(sub_mod(a0, tmp, q0.q), inv_qlast, q0), z, q0.q);
-  };
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const size_t p = k * 2 + j;
-    v2 r = {0, 0};
-    if (j == 1 || any_kept) {  // of removed c0 coefficients nothing is read
-      const v2 a0 = ld2(acc + ((p * 2) << logN) + i), a1 = ld2(acc + ((p * 2 + 1) << logN) + i);
-      const v2 z = ld2(zero + (p << logN) + i);
-      r.x = switched(a0.x, a1.x, z.x), r.y = switched(a0.y, a1.y, z.y);
-      if (j == 1) {
-        if (e1) {
-          const longlong2 e = *reinterpret_cast<const longlong2 *>(e1 + idx);
-          r.x = add_mod(r.x, signed_to_mod(e.x, q0.q), q0.q), r.y = add_mod(r.y, signed_to_mod(e.y, q0.q), q0.q);
-        }
-        r.x &= mask1, r.y &= mask1;
-      } else {
-        r.x = kept[0] ? sub_mod(r.x, m.x, q0.q) & mask0 : 0;
-        r.y = kept[1] ? sub_mod(r.y, m.y, q0.q) & mask0 : 0;
-      }
-    }
-    *reinterpret_cast<v2 *>(out + (p << logN) + i) = r;
-  }
 }
 
 __global__ __launch_bounds__(256) void slot_scatter_kernel(const u64 *__restrict__ vals, u64 *__restrict__ pts,
@@ -742,15 +678,14 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   const size_t N = ctx->N;
-  StreamBuf u(s), zero(s);
+  StreamBuf u(s);
   MMH_HIP(u.alloc(n * N * 8));
-  MMH_HIP(zero.alloc(n * 2 * N * 8));
   if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
   CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
-  CHECK_RC(ntt_inv_product_dispatch(ctx, u.as<u64>(), d_pk_ntt_last, zero.as<u64>(), n, 1, s));
-  LAUNCH(reshare_finish_kernel, n * N / 2, s, d_acc, zero.as<u64>(), d_e1, d_mask, d_out, n * N, ctx->logN,
-         ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep, keep_period ? keep_period : 1,
-         ctx->d_mods, d_share_dst, share_plane, d_share_out, ctx->bfv);
+  // u * pk_j back to coefficient form and, coefficient by coefficient, into the tail (ReshareSink, ntt.hip): the
+  // encryption of zero is never written
+  CHECK_RC(ntt_inv_product_reshare(ctx, u.as<u64>(), d_pk_ntt_last, n, d_acc, d_e1, d_mask, d_out, d_keep,
+                                   keep_period, d_share_dst, share_plane, d_share_out, s));
   return MMH_OK;
 }
 }  // namespace mmh

@@ -13,6 +13,7 @@
 // LDS image: element j lives at j + (j >> 4) (one 8-byte pad per 16 elements), which makes
 // every access pattern of the three passes bank-conflict free for ds_read_b64/ds_write_b64.
 #include "common.hpp"
+#include "bfv_device.hpp"
 
 namespace mmh {
 
@@ -392,9 +393,117 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   store_from_lds<LOGN>(a, lds);
 }
 
+// What becomes of the coefficients an inverse transform produces.
+//   SINK_STORE    written in place.
+//   SINK_RESHARE  unit (p, j) is component j of the pk-encryption of zero of output ciphertext p at the last level
+//                 (PROD source); its coefficients go straight into the re-sharing tail of the approximate build
+//                 (hom_conv2d_ss.cc:761-788, :392-441, :108-140):
+//                   out = truncate(mod_switch(acc) + zero + (0, e1) - (mask, 0)), unused coefficients of c0 cleared,
+//                 and the other party's share is the mask's scale-and-round at the target coefficients.  The
+//                 encryption of zero never exists in memory.  acc [n][2][2][N] coefficient form at the first level,
+//                 mask [n][N] mod q0, e1 signed, out [n][2][N].
+enum { SINK_STORE = 0, SINK_RESHARE = 1 };
+struct ReshareSink {
+  const u64 *acc;
+  const int64_t *e1;
+  const u64 *mask;
+  u64 *out;
+  u64 inv_qlast, mask0, mask1;
+  const uint8_t *keep;
+  size_t keep_period;
+  const int *share_dst;
+  size_t share_plane;
+  u64 *share_out;
+  BfvConsts b;
+};
+template <int LOGN, int SINK>
+struct Emitter {
+  static constexpr int EA = 1 << (LOGN - 8), H = 4;  // coefficients per lane, and per batch of loads
+  u64 *__restrict__ a;    // SINK_STORE: the polynomial itself
+  const ReshareSink &f;
+  const DevMod *__restrict__ mods;
+  size_t p;               // output ciphertext, component
+  int j;
+  __device__ __forceinline__ Emitter(u64 *a_, const ReshareSink &f_, const DevMod *mods_, u32 unit)
+      : a(a_), f(f_), mods(mods_), p(unit >> 1), j(unit & 1) {}
+  // coefficients k*256 + t of the unit, canonical modulo this limb's q.  The tail parks them in the lane's own
+  // cells of the LDS image (nobody else reads those in the last pass) and walks them in batches of H: all loads
+  // of a batch ahead of its arithmetic and its stores, one memory round trip per batch instead of one per
+  // coefficient, and the batch loop stays a loop.
+  __device__ __forceinline__ void operator()(int t, const u64 (&zr)[EA], u64 *lds) const {
+    if (SINK == SINK_STORE) {
+#pragma unroll
+      for (int k = 0; k < EA; ++k) a[k * 256 + t] = zr[k];
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = zr[k];
+    const u64 *z = lds + pad(t);  // coefficient k*256 + t at z[17 * 16 * k]
+    constexpr int ZS = 256 + 16;
+    const DevMod &q0 = mods[0];
+    const u64 q1 = mods[1].q, half = q1 >> 1, half0 = reduce64(half, q0);
+    const u64 *__restrict__ acc0 = f.acc + (((p * 2 + j) * 2) << LOGN), *__restrict__ acc1 = acc0 + (size_t(1) << LOGN);
+    u64 *__restrict__ dst = f.out + ((p * 2 + j) << LOGN);
+    auto switched = [&](u64 a0, u64 a1, u64 zz) {  // divide_and_round_q_last, then the encryption of zero
+      const u64 last = csub(a1 + half, q1);
+      const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
+      return add_mod(mul_mod(sub_mod(a0, tmp, q0.q), f.inv_qlast, q0), zz, q0.q);
+    };
+    if (j == 1) {
+      const int64_t *__restrict__ e1 = f.e1 ? f.e1 + (p << LOGN) : nullptr;
+#pragma unroll 1
+      for (int h = 0; h < EA; h += H) {
+        u64 a0[H], a1[H];
+        int64_t e[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+          const int i = (h + k) * 256 + t;
+          a0[k] = acc0[i], a1[k] = acc1[i], e[k] = e1 ? e1[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+          const u64 r = add_mod(switched(a0[k], a1[k], z[(h + k) * ZS]), signed_to_mod(e[k], q0.q), q0.q);
+          dst[(h + k) * 256 + t] = r & f.mask1;
+        }
+      }
+      return;
+    }
+    const size_t kp0 = (p % f.keep_period) << LOGN;
+    const u64 *__restrict__ mask = f.mask + (p << LOGN);
+    u64 *__restrict__ share = f.share_out + (p / f.keep_period) * f.share_plane;
+#pragma unroll 1
+    for (int h = 0; h < EA; h += H) {
+      bool kept[H];
+      int d[H];
+      u64 m[H], a0[H], a1[H];
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        const int i = (h + k) * 256 + t;
+        kept[k] = !f.keep || f.keep[kp0 + i] != 0;
+        d[k] = f.share_dst ? f.share_dst[kp0 + i] : -1;
+        m[k] = mask[i];
+      }
+#pragma unroll
+      for (int k = 0; k < H; ++k) {  // of removed c0 coefficients nothing more is read
+        const int i = (h + k) * 256 + t;
+        a0[k] = kept[k] ? acc0[i] : 0, a1[k] = kept[k] ? acc1[i] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        if (d[k] >= 0) {  // the other party's share: scale-and-round of the mask at the target coefficients
+          const u64 x[2] = {m[k], 0};
+          share[d[k]] = behz_round(x, f.b, f.b.lv[1], mods);
+        }
+        const u64 r = sub_mod(switched(a0[k], a1[k], z[(h + k) * ZS]), m[k], q0.q) & f.mask0;
+        dst[(h + k) * 256 + t] = kept[k] ? r : 0;
+      }
+    }
+  }
+};
+
 // Inverse transform of one limb with q < 2^49 in double precision (LDS already holds the input).
-template <int LOGN>
-__device__ __forceinline__ void ntt_inv_f64(u64 *__restrict__ a, const DevMod &M,
+template <int LOGN, class Emit>
+__device__ __forceinline__ void ntt_inv_f64(const Emit &emit, const DevMod &M,
                                             const ulonglong2 *__restrict__ tw, u64 *lds_u) {
   constexpr int RA = LOGN - 8, EA = 1 << RA, REPS = (1 << LOGN) / 4096;
   double *lds = reinterpret_cast<double *>(lds_u);
@@ -435,18 +544,22 @@ __device__ __forceinline__ void ntt_inv_f64(u64 *__restrict__ a, const DevMod &M
     load_twiddles_f64<RA, 0>(tw, 0, wA);
     inv_radix_f64<RA, 8>(x, wA, m);
     const double ninv = (double)M.ninv;  // exact: below q < 2^49
+    u64 z[EA];
 #pragma unroll
-    for (int k = 0; k < EA; ++k) a[k * 256 + t] = f64_canonical(f64_mulmod(ninv, x[k], m), m);
+    for (int k = 0; k < EA; ++k) z[k] = f64_canonical(f64_mulmod(ninv, x[k], m), m);
+    emit(t, z, lds_u);
   }
 }
 
 // PROD: polynomial (k, j, l) of the output is the inverse transform of src.p[k][l] (.) src.p2[j][l], the dyadic
 // product formed while loading (encrypt_zero's u * pk_j without a pass of its own); else in place.
-template <int LOGN, bool FOLD, bool PROD = false>
-__global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
+// (second launch bound: the waves per SIMD that the LDS image allows anyway, so that the tail's batched loads are
+// fitted into 128 registers instead of costing a workgroup per CU)
+template <int LOGN, bool FOLD, bool PROD = false, int SINK = SINK_STORE>
+__global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void ntt_inv_kernel(u64 *__restrict__ data,
                                                       const DevMod *__restrict__ mods,
                                                       const ulonglong2 *__restrict__ tables,
-                                                      int limbs, int mod_base, NttSource src) {
+                                                      int limbs, int mod_base, NttSource src, ReshareSink fin) {
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
@@ -478,8 +591,9 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     }
   }
   __syncthreads();
+  const Emitter<LOGN, SINK> emit(a, fin, mods, blockIdx.x);  // (SINK_RESHARE runs with limbs == 1)
   if (M.f64) {  // uniform over the workgroup
-    ntt_inv_f64<LOGN>(a, M, tw, lds);
+    ntt_inv_f64<LOGN>(emit, M, tw, lds);
     return;
   }
   const Reducer<FOLD> rd(M);
@@ -519,8 +633,8 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(u64 *__restrict__ data,
     inv_radix<RA, 0, 8, FOLD, true>(x, wA, nq, rd);
     const u64 ninv = M.ninv, ninv_sh = M.ninv_sh;
 #pragma unroll
-    for (int k = 0; k < EA; ++k)
-      a[k * 256 + t] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
+    for (int k = 0; k < EA; ++k) x[k] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
+    emit(t, x, lds);
   }
 }
 
@@ -529,13 +643,40 @@ static constexpr size_t lds_bytes() {
   return ((size_t(1) << LOGN) + (size_t(1) << (LOGN - 4))) * sizeof(u64);
 }
 
-// mode: SRC_* for a forward transform, -1 for the inverse (in place), -2 for the inverse of a product
+template <int LOGN, class K>
+static int launch_inverse(K kern, u64 *d, const mmh_ctx *ctx, size_t blocks, int limbs, int mod_base,
+                          const NttSource &src, const ReshareSink &fin, hipStream_t s) {
+  if (lds_bytes<LOGN>() > 48 * 1024)  // per device and cheap: set on every launch
+    MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<LOGN>()));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes<LOGN>(), s, d, ctx->d_mods,
+                     ctx->d_tables, limbs, mod_base, src, fin);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+// mode: SRC_* for a forward transform, -1 for the inverse (in place), -2 for the inverse of a product, -3 for the
+// inverse of a product whose coefficients feed the re-sharing tail (fin)
 template <int LOGN>
 static int launch(int mode, bool fold, u64 *d, const mmh_ctx *ctx, size_t blocks, int limbs, int mod_base,
-                  const NttSource &src, hipStream_t s) {
-  auto kern = mode == -2 ? (fold ? ntt_inv_kernel<LOGN, true, true> : ntt_inv_kernel<LOGN, false, true>)
-              : mode < 0 ? (fold ? ntt_inv_kernel<LOGN, true> : ntt_inv_kernel<LOGN, false>)
-              : mode == SRC_PLAIN
+                  const NttSource &src, hipStream_t s, const ReshareSink *fin = nullptr) {
+  if (mode == -3)
+    return fold ? launch_inverse<LOGN>(ntt_inv_kernel<LOGN, true, true, SINK_RESHARE>, d, ctx, blocks, limbs, mod_base,
+                                       src, *fin, s)
+                : launch_inverse<LOGN>(ntt_inv_kernel<LOGN, false, true, SINK_RESHARE>, d, ctx, blocks, limbs,
+                                       mod_base, src, *fin, s);
+  if (mode == -2)
+    return fold ? launch_inverse<LOGN>(ntt_inv_kernel<LOGN, true, true>, d, ctx, blocks, limbs, mod_base, src,
+                                       ReshareSink{}, s)
+                : launch_inverse<LOGN>(ntt_inv_kernel<LOGN, false, true>, d, ctx, blocks, limbs, mod_base, src,
+                                       ReshareSink{}, s);
+  if (mode == -1)
+    return fold ? launch_inverse<LOGN>(ntt_inv_kernel<LOGN, true>, d, ctx, blocks, limbs, mod_base, src,
+                                       ReshareSink{}, s)
+                : launch_inverse<LOGN>(ntt_inv_kernel<LOGN, false>, d, ctx, blocks, limbs, mod_base, src,
+                                       ReshareSink{}, s);
+  auto kern = 
+                mode == SRC_PLAIN
                   ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_PLAIN> : ntt_fwd_kernel<LOGN, false, SRC_PLAIN>)
               : mode == SRC_FILTER
                   ? (fold ? ntt_fwd_kernel<LOGN, true, SRC_FILTER> : ntt_fwd_kernel<LOGN, false, SRC_FILTER>)
@@ -552,15 +693,15 @@ static int launch(int mode, bool fold, u64 *d, const mmh_ctx *ctx, size_t blocks
 }
 
 static int dispatch(const mmh_ctx *ctx, int mode, u64 *d, const NttSource &src, size_t n_polys, int limbs,
-                    int mod_base, hipStream_t s) {
+                    int mod_base, hipStream_t s, const ReshareSink *fin = nullptr) {
   const size_t blocks = n_polys * (size_t)limbs;
   if (blocks == 0) return MMH_OK;
   MMH_REQUIRE(blocks <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
   bool fold = true;  // every modulus of this launch must have the 2^b - c shape for the fast reducer
   for (int l = 0; l < limbs; ++l) fold = fold && ctx->h_mods[mod_base + l].fold_c != 0;
   switch (ctx->logN) {
-    case 12: return launch<12>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s);
-    case 13: return launch<13>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s);
+    case 12: return launch<12>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s, fin);
+    case 13: return launch<13>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s, fin);
     default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
   }
 }
@@ -603,6 +744,19 @@ int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *
   NttSource src{};
   src.p = d_u_ntt, src.p2 = d_key;
   return dispatch(ctx, -2, d_out, src, n * 2, limbs, 0, s);
+}
+
+// The re-sharing tail of n output ciphertexts from u in NTT form: components (p, j) = INTT(u_ntt[p] (.) key[j])
+// at the last level go through ReshareSink into out / share_out; nothing else is written.
+int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, size_t n, const u64 *d_acc,
+                            const int64_t *d_e1, const u64 *d_mask, u64 *d_out, const uint8_t *d_keep,
+                            size_t keep_period, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
+                            hipStream_t s) {
+  NttSource src{};
+  src.p = d_u_ntt, src.p2 = d_key;
+  ReshareSink fin{d_acc, d_e1, d_mask, d_out, ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep,
+                  keep_period ? keep_period : 1, d_share_dst, share_plane, d_share_out, ctx->bfv};
+  return dispatch(ctx, -3, d_out, src, n * 2, 1, 0, s, &fin);
 }
 
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,
