@@ -41,10 +41,13 @@ def pmc_traffic(ntts_per_launch):
 
 
 def cpu_baseline(seconds=12.0):
-    """oracle (a port, not HEXL) forward NTT N=4096 on host cores, bounded sample"""
+    """oracle (a port, not HEXL) forward NTT N=4096 on host cores, bounded sample; the AVX-512 restatement of the
+    same butterflies (oracle/mm_oracle_avx512.c, 8 lanes, 64-bit products from 32-bit halves like HEXL's 64-bit
+    path) where the host has it, the scalar C otherwise: `isa` says which"""
     import numpy as np
     from tests.oracle_binding import OracleCtx, A, uniform_mod
     o = OracleCtx(4096, (60, 49), 0)
+    vector = bool(o.lib.mmo_set_vector_isa(1))
     threads = min(16, len(os.sched_getaffinity(0)))
     n_polys = 64 * threads
     a = np.stack([np.stack([uniform_mod(1 + l, 4096, q) for l, q in enumerate(o.q)])] * n_polys)
@@ -55,7 +58,8 @@ def cpu_baseline(seconds=12.0):
         done += 2 * n_polys
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "NTT/s", "cores": threads, "kind": "port",
-            "sample": f"{done} forward limb-NTTs N=4096 (oracle Harvey/Shoup C, OpenMP) in {dt:.1f}s"}
+            "isa": "avx512f+dq, 8 x u64 lanes" if vector else "scalar x86-64",
+            "sample": f"{done} forward limb-NTTs N=4096 (oracle Harvey/Shoup C, OpenMP x{threads}) in {dt:.1f}s"}
 
 
 def cpu_homconv_ms(reps=3):
@@ -67,6 +71,7 @@ def cpu_homconv_ms(reps=3):
     from tests.oracle_binding import OracleCtx, A, uniform_mod, splitmix64
     t, N, M, Cs = 1 << 37, 4096, 64, 64
     o = OracleCtx(N, (60, 49), t)
+    o.lib.mmo_set_vector_isa(1)   # the AVX-512 transforms where the host has them (same bits)
     threads = min(16, len(os.sched_getaffinity(0)))
     image = np.stack([np.stack([np.stack([uniform_mod(9 * k + 2 * j + l, N, q) for l, q in enumerate(o.q)])
                                 for j in range(2)]) for k in range(Cs)])

@@ -10,6 +10,7 @@
 // result at mat_C + r * input_cols.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "mm_gemini/cheetah_linear.h"
 #include "mm_gemini/truncation.h"
@@ -25,7 +26,12 @@ struct Library {
   uint64_t prime_mod = 0, field_mod = 0;  // 2^bitlength and the table prime (constants.h:45-50)
   bool kIsSharedInput = true;             // networks set it false around their first layer
   gemini::CheetahLinear *cheetah_linear = nullptr;
-  Truncation *truncation = nullptr;       // one conversion object (the reference keeps one per thread)
+  Truncation *truncation = nullptr;       // truncationArr[0] of the reference (library_fixed_uniform.cpp:1556)
+  // One conversion object per worker thread, each on its own channel, odd ones built with the roles swapped
+  // (party 3 - party: library_fixed_uniform.cpp:1540-1554), so that both directions of the link carry COT
+  // corrections.  Ring2Field / Field2Ring / Field2Ring_with_Truncate split their range over them exactly as
+  // library_fixed_uniform_cheetah.cpp:492-565 does; empty = the single object above takes the whole range.
+  std::vector<Truncation *> truncationArr;
 
   uint64_t getRingElt(int64_t x) const { return (uint64_t)x & (prime_mod - 1); }
   uint64_t getFieldElt(int64_t x) const {

@@ -67,8 +67,12 @@ class IdealFerret : public RandomCOT {
 
 class SilentOT : public COT {
  public:
-  SilentOT(RandomCOT *ferret, IOChannel *io, uint64_t prg_seed = std::random_device{}())
-      : ferret_(ferret), io_(io), prg_(prg_seed) {}
+  // The MITCCRH start point S of every call travels in the clear and must be unpredictable (silent_ot.h:91-95 draws
+  // it from emp-tool's AES-based PRG, itself seeded from the OS): 16 bytes of /dev/urandom per call.  A test may ask
+  // for a repeatable stream instead by passing a seed.
+  SilentOT(RandomCOT *ferret, IOChannel *io) : ferret_(ferret), io_(io) {}
+  SilentOT(RandomCOT *ferret, IOChannel *io, uint64_t test_seed)
+      : ferret_(ferret), io_(io), seeded_(true), prg_(test_seed) {}
   // silent_ot.h:85, :129, :168, :209 (sci::OT<T> forwards send_cot .. recv_cot_prime to them, ot.h:80-93)
   void send_ot_cam_cc(uint64_t *data0, const uint64_t *corr, int64_t length, int l) { send(data0, corr, length, l, 0); }
   void send_ot_cam_cc_prime(uint64_t *data0, const uint64_t *corr, int64_t length, uint64_t p) {
@@ -88,8 +92,10 @@ class SilentOT : public COT {
  private:
   void send(uint64_t *data0, const uint64_t *corr, int64_t n, int l, uint64_t p);
   void recv(uint64_t *data, const bool *b, int64_t n, int l, uint64_t p);
+  void fresh_seed(uint64_t seed[2]);
   RandomCOT *ferret_;
   IOChannel *io_;
-  std::mt19937_64 prg_;
+  bool seeded_ = false;
+  std::mt19937_64 prg_;  // test streams only
 };
 }  // namespace mm

@@ -79,7 +79,7 @@ Code HomBNSS::encryptVector(const Tensor<uint64_t> &in_vec, const Meta &meta, st
   const size_t N = poly_degree_, L = simd_context_->coeff_modulus_size(), ct = 2 * L * N;
   const size_t n = (size_t)meta.vec_shape.length(), n_ct = n_simd_cts(meta, N);
   Dev vec(n), a(n_ct * L * N), e(n_ct * N), cts(n_ct * ct);
-  MM_TRY(vec.rc | a.rc | e.rc | cts.rc);
+  MM_TRY(first_rc({vec.rc, a.rc, e.rc, cts.rc}));
   MM_TRY(vec.up(in_vec.data(), n));
   uint64_t sid;
   {
@@ -105,7 +105,7 @@ Code HomBNSS::encodeVector(const Tensor<uint64_t> &in_vec, const Meta &meta, std
   MM_ENSURE(in_vec.shape().IsSameSize(meta.vec_shape), Code::ERR_DIM_MISMATCH);
   const size_t N = poly_degree_, n = (size_t)meta.vec_shape.length(), n_ct = n_simd_cts(meta, N);
   Dev vec(n), pts(n_ct * N);
-  MM_TRY(vec.rc | pts.rc);
+  MM_TRY(first_rc({vec.rc, pts.rc}));
   MM_TRY(vec.up(in_vec.data(), n));
   MM_TRY(mmh_bn_encode_vector(simd_context_->raw(), vec.p, n, pts.p, nullptr));
   out.resize(n_ct);
@@ -129,7 +129,7 @@ Code HomBNSS::server_simd(const uint64_t *h_cts, size_t n_cts_in, const std::vec
   const size_t N = poly_degree_, L = simd_context_->coeff_modulus_size(), ct = 2 * L * N;
   const size_t n = (size_t)meta.vec_shape.length(), n_ct = n_simd_cts(meta, N);
   Dev cts(n_cts_in * ct), d_pts(std::max<size_t>(1, pts.size()) * N), rnd(n), out_cts(n_ct * 2 * N), share(n);
-  MM_TRY(cts.rc | d_pts.rc | rnd.rc | out_cts.rc | share.rc);
+  MM_TRY(first_rc({cts.rc, d_pts.rc, rnd.rc, out_cts.rc, share.rc}));
   MM_TRY(cts.up(h_cts, n_cts_in * ct));
   for (size_t i = 0; i < pts.size(); ++i) {
     MM_ENSURE(pts[i]->coeff_count() == N, Code::ERR_INTERNAL);
@@ -218,7 +218,7 @@ Code HomBNSS::decryptToVector(const std::vector<mm::he::Ciphertext> &in_vec, con
   const size_t N = poly_degree_, n = (size_t)meta.vec_shape.length(), n_ct = n_simd_cts(meta, N);
   MM_ENSURE(in_vec.size() == n_ct, Code::ERR_INVALID_ARG);
   Dev cts(n_ct * 2 * N), res(n);
-  MM_TRY(cts.rc | res.rc);
+  MM_TRY(first_rc({cts.rc, res.rc}));
   for (size_t k = 0; k < n_ct; ++k) {
     MM_ENSURE(in_vec[k].size() == 2 && in_vec[k].coeff_modulus_size() == 1 && in_vec[k].poly_modulus_degree() == N,
               Code::ERR_INTERNAL);
@@ -246,7 +246,7 @@ Code HomBNSS::encodeTensor(const Tensor<uint64_t> &in_tensor, const Meta &meta, 
   MM_TRY(mmh_bn_tensor_count(direct_context_->raw(), &m, &n_ct, nullptr));
   const size_t N = poly_degree_, words = (size_t)in_tensor.NumElements();
   Dev x(words), pts(n_ct * N);
-  MM_TRY(x.rc | pts.rc);
+  MM_TRY(first_rc({x.rc, pts.rc}));
   MM_TRY(x.up(in_tensor.data(), words));
   MM_TRY(mmh_bn_encode_tensor(direct_context_->raw(), &m, x.p, pts.p, nullptr));
   out.resize(n_ct);
@@ -268,7 +268,7 @@ Code HomBNSS::encryptTensor(const Tensor<uint64_t> &in_tensor, const Meta &meta,
   const size_t N = poly_degree_, L = direct_context_->coeff_modulus_size(), ct = 2 * L * N;
   const size_t words = (size_t)in_tensor.NumElements();
   Dev x(words), a(n_ct * L * N), e(n_ct * N), cts(n_ct * ct);
-  MM_TRY(x.rc | a.rc | e.rc | cts.rc);
+  MM_TRY(first_rc({x.rc, a.rc, e.rc, cts.rc}));
   MM_TRY(x.up(in_tensor.data(), words));
   uint64_t sid;
   {
@@ -303,7 +303,7 @@ Code HomBNSS::bn_direct(const std::vector<mm::he::Ciphertext> &tensor_share0,
   const size_t words = (size_t)meta.ishape.num_elements(), C = (size_t)scales.length();
   Dev cts(n_ct * ct), pts(meta.is_shared_input ? n_ct * N : 1), d_scales(C);
   Dev u(n_ct * N), e0(n_ct * N), e1(n_ct * N), share1(words), out_cts(n_ct * 2 * N);
-  MM_TRY(cts.rc | pts.rc | d_scales.rc | u.rc | e0.rc | e1.rc | share1.rc | out_cts.rc);
+  MM_TRY(first_rc({cts.rc, pts.rc, d_scales.rc, u.rc, e0.rc, e1.rc, share1.rc, out_cts.rc}));
   for (size_t i = 0; i < n_ct; ++i) {
     MM_ENSURE(tensor_share0[i].size() == 2 && tensor_share0[i].coeff_modulus_size() == L &&
                   tensor_share0[i].poly_modulus_degree() == N,
@@ -349,7 +349,7 @@ Code HomBNSS::decryptToTensor(const std::vector<mm::he::Ciphertext> &in_vec, con
   MM_ENSURE(in_vec.size() == n_ct, Code::ERR_DIM_MISMATCH);
   const size_t N = poly_degree_, words = (size_t)meta.ishape.num_elements();
   Dev cts(n_ct * 2 * N), res(words);
-  MM_TRY(cts.rc | res.rc);
+  MM_TRY(first_rc({cts.rc, res.rc}));
   for (size_t k = 0; k < n_ct; ++k) {
     MM_ENSURE(in_vec[k].size() == 2 && in_vec[k].coeff_modulus_size() == 1 && in_vec[k].poly_modulus_degree() == N,
               Code::ERR_INTERNAL);

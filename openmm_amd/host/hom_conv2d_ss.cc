@@ -52,7 +52,7 @@ void mm::he::GenerateKeys(const Context &context, SecretKey &sk, PublicKey &pk) 
   uint32_t key[8];
   if (!gemini::seed_from_os(key)) throw std::runtime_error("GenerateKeys: cannot seed the sampler");
   Dev s(N), a(L * N), e(N), d_sk(L * N), d_pk(2 * L * N);
-  must(s.rc | a.rc | e.rc | d_sk.rc | d_pk.rc, "mmh_malloc");
+  must(gemini::first_rc({s.rc, a.rc, e.rc, d_sk.rc, d_pk.rc}), "mmh_malloc");
   must(mmh_sample_ternary(key, 1, (int64_t *)s.p, N, nullptr), "sample_ternary");
   must(mmh_sample_uniform(context.raw(), 0, key, 2, a.p, 1, nullptr), "sample_uniform");
   must(mmh_sample_noise(key, 3, (int64_t *)e.p, N, nullptr), "sample_noise");
@@ -130,7 +130,7 @@ Code HomConv2DSS::encryptImage(const Tensor<uint64_t> &img, const Meta &meta,
   MM_TRY(plan_info(p, pi));
   const size_t N = poly_degree(), L = context_->coeff_modulus_size(), ct = 2 * L * N;
   Dev d_img((size_t)img.NumElements()), a(pi.n_in * L * N), e(pi.n_in * N), cts(pi.n_in * ct);
-  MM_TRY(d_img.rc | a.rc | e.rc | cts.rc);
+  MM_TRY(first_rc({d_img.rc, a.rc, e.rc, cts.rc}));
   MM_TRY(d_img.up(img.data(), (size_t)img.NumElements()));
   uint64_t sid;
   {
@@ -159,7 +159,7 @@ Code HomConv2DSS::encodeImage(const Tensor<uint64_t> &img, const Meta &meta,
   MM_TRY(plan_info(p, pi));
   const size_t N = poly_degree();
   Dev d_img((size_t)img.NumElements()), pts(pi.n_in * N);
-  MM_TRY(d_img.rc | pts.rc);
+  MM_TRY(first_rc({d_img.rc, pts.rc}));
   MM_TRY(d_img.up(img.data(), (size_t)img.NumElements()));
   MM_TRY(mmh_conv_encode_image(p, d_img.p, pts.p, nullptr));
   encoded_share.resize(pi.n_in);
@@ -183,7 +183,7 @@ Code HomConv2DSS::encodeFilters(const std::vector<Tensor<uint64_t>> &filters, co
   MM_TRY(plan_info(p, pi));
   const size_t N = poly_degree(), fw = (size_t)meta.fshape.num_elements();
   Dev d_f(M * fw), pts(M * pi.n_cs * N);
-  MM_TRY(d_f.rc | pts.rc);
+  MM_TRY(first_rc({d_f.rc, pts.rc}));
   for (size_t m = 0; m < M; ++m) MM_TRY(d_f.up(filters[m].data(), fw, m * fw));
   MM_TRY(mmh_conv_encode_filters(p, d_f.p, pts.p, nullptr));
   encoded_filters.assign(M, std::vector<mm::he::Plaintext>(pi.n_cs));
@@ -225,7 +225,7 @@ Code HomConv2DSS::conv2DSS(const std::vector<mm::he::Ciphertext> &img_share0,
   Dev u(pi.n_out * N), e1(pi.n_out * N), mask(pi.n_out * N), out_cts(pi.n_out * 2 * N);
   const size_t out_words = (size_t)(pi.oshape[0] * pi.oshape[1] * pi.oshape[2]);
   Dev out_share(out_words);
-  MM_TRY(cts.rc | share.rc | fpts.rc | u.rc | e1.rc | mask.rc | out_cts.rc | out_share.rc);
+  MM_TRY(first_rc({cts.rc, share.rc, fpts.rc, u.rc, e1.rc, mask.rc, out_cts.rc, out_share.rc}));
   for (size_t i = 0; i < pi.n_in; ++i) MM_TRY(cts.up(img_share0[i].data(), ct, i * ct));
   if (meta.is_shared_input)
     for (size_t i = 0; i < pi.n_in; ++i) {
@@ -268,7 +268,7 @@ Code HomConv2DSS::decryptToTensor(const std::vector<mm::he::Ciphertext> &enc_ten
   Dev cts(pi.n_out * 2 * N);
   const size_t out_words = (size_t)(pi.oshape[0] * pi.oshape[1] * pi.oshape[2]);
   Dev res(out_words);
-  MM_TRY(cts.rc | res.rc);
+  MM_TRY(first_rc({cts.rc, res.rc}));
   for (size_t k = 0; k < pi.n_out; ++k) {
     MM_ENSURE(enc_tensor[k].size() == 2 && enc_tensor[k].coeff_modulus_size() == 1 &&
                   enc_tensor[k].poly_modulus_degree() == N,

@@ -54,7 +54,7 @@ Code HomFCSS::encryptInputVector(const Tensor<uint64_t> &vec, const Meta &meta,
   MM_TRY(mmh_fc_plan_info(p, nullptr, &n_in, &n_out));
   const size_t N = poly_degree(), L = context_->coeff_modulus_size(), ct = 2 * L * N, len = (size_t)vec.NumElements();
   Dev d_vec(len), a(n_in * L * N), e(n_in * N), cts(n_in * ct);
-  MM_TRY(d_vec.rc | a.rc | e.rc | cts.rc);
+  MM_TRY(first_rc({d_vec.rc, a.rc, e.rc, cts.rc}));
   MM_TRY(d_vec.up(vec.data(), len));
   uint64_t sid;
   {
@@ -84,7 +84,7 @@ Code HomFCSS::encodeInputVector(const Tensor<uint64_t> &vec, const Meta &meta,
   MM_TRY(mmh_fc_plan_info(p, nullptr, &n_in, nullptr));
   const size_t N = poly_degree(), len = (size_t)vec.NumElements();
   Dev d_vec(len), pts(n_in * N);
-  MM_TRY(d_vec.rc | pts.rc);
+  MM_TRY(first_rc({d_vec.rc, pts.rc}));
   MM_TRY(d_vec.up(vec.data(), len));
   MM_TRY(mmh_fc_encode_input(p, d_vec.p, pts.p, nullptr));
   encoded_share.resize(n_in);
@@ -106,7 +106,7 @@ Code HomFCSS::encodeWeightMatrix(const Tensor<uint64_t> &w, const Meta &meta,
   MM_TRY(mmh_fc_plan_info(p, nullptr, &n_in, &n_out));
   const size_t N = poly_degree(), len = (size_t)w.NumElements();
   Dev d_w(len), pts(n_out * n_in * N);
-  MM_TRY(d_w.rc | pts.rc);
+  MM_TRY(first_rc({d_w.rc, pts.rc}));
   MM_TRY(d_w.up(w.data(), len));
   MM_TRY(mmh_fc_encode_weights(p, d_w.p, pts.p, nullptr));
   encoded_share.assign(n_out, std::vector<mm::he::Plaintext>(n_in));
@@ -138,7 +138,7 @@ Code HomFCSS::matVecMul(const std::vector<std::vector<mm::he::Plaintext>> &matri
   const size_t rows = (size_t)meta.weight_shape.rows();
   Dev cts(n_in * ct), share(meta.is_shared_input ? n_in * N : 1), wpts(n_out * n_in * N);
   Dev u(n_out * N), e1(n_out * N), mask(n_out * N), out_cts(n_out * 2 * N), out_share(rows);
-  MM_TRY(cts.rc | share.rc | wpts.rc | u.rc | e1.rc | mask.rc | out_cts.rc | out_share.rc);
+  MM_TRY(first_rc({cts.rc, share.rc, wpts.rc, u.rc, e1.rc, mask.rc, out_cts.rc, out_share.rc}));
   for (size_t i = 0; i < n_in; ++i) {
     MM_ENSURE(vec_share0[i].size() == 2 && vec_share0[i].coeff_modulus_size() == L &&
                   vec_share0[i].poly_modulus_degree() == N,
@@ -183,7 +183,7 @@ Code HomFCSS::decryptToVector(const std::vector<mm::he::Ciphertext> &enc_vector,
   MM_ENSURE(enc_vector.size() == n_out, Code::ERR_INVALID_ARG);
   const size_t N = poly_degree(), rows = (size_t)meta.weight_shape.rows();
   Dev cts(n_out * 2 * N), res(rows);
-  MM_TRY(cts.rc | res.rc);
+  MM_TRY(first_rc({cts.rc, res.rc}));
   for (size_t k = 0; k < n_out; ++k) {
     MM_ENSURE(enc_vector[k].size() == 2 && enc_vector[k].coeff_modulus_size() == 1 &&
                   enc_vector[k].poly_modulus_degree() == N,

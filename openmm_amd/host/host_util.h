@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <initializer_list>
 #include <vector>
 
 #include "mm_gemini/core.h"
@@ -17,6 +18,12 @@ namespace {
     const int rc_ = (expr);                           \
     if (rc_ != MMH_OK) return static_cast<Code>(rc_); \
   } while (0)
+// several allocations checked at once: the first failure's code (codes are an enumeration, not flags)
+inline int first_rc(std::initializer_list<int> rcs) {
+  for (int rc : rcs)
+    if (rc != MMH_OK) return rc;
+  return MMH_OK;
+}
 #define MM_ENSURE(cond, code) \
   do {                        \
     if (!(cond)) return code; \

@@ -2,6 +2,9 @@
 // (SCI/src/library_fixed_uniform_cheetah.cpp:70-600); see include/mm_gemini/library.h.
 #include "mm_gemini/library.h"
 
+#include <exception>
+#include <thread>
+
 #include <algorithm>
 #include <cstdio>
 #include <stdexcept>
@@ -103,16 +106,48 @@ void Library::BatchNorm(int32_t B, int32_t H, int32_t W, int32_t C, const intTyp
   if (cheetah_linear->party() == kServer) cheetah_linear->safe_erase(scale_vec.data(), scale_vec.NumElements());
 }
 
-// :492-565.  The reference splits the range over num_threads Truncation objects (each with its own
-// socket); the conversions here are single batched device calls, so one object takes the whole range.
+// :492-565: the range split over num_threads = truncationArr.size() conversion objects, one std::thread each, chunks
+// of (size / (8 * num_threads)) * 8 elements with the remainder on the last thread (:494-502); every object runs
+// its own batched device calls on its own channel.  With no array set the single object takes the whole range.
+template <class Fn>
+static void split_over_threads(const Library &lib, int32_t size, intType *in, intType *out, Fn &&one) {
+  const int nt = (int)lib.truncationArr.size();
+  if (nt == 0) {
+    one(*lib.truncation, size, in, out);
+    return;
+  }
+  const int32_t chunk = (size / (8 * nt)) * 8;
+  std::vector<std::thread> workers;
+  std::vector<std::exception_ptr> failed(nt);
+  for (int i = 0; i < nt; ++i) {
+    const int32_t offset = i * chunk, cur = i == nt - 1 ? size - offset : chunk;
+    if (cur <= 0) continue;  // (both parties skip the same empty chunks)
+    workers.emplace_back([&, i, offset, cur] {
+      try {
+        one(*lib.truncationArr[i], cur, in + offset, out + offset);
+      } catch (...) {
+        failed[i] = std::current_exception();
+      }
+    });
+  }
+  for (auto &w : workers) w.join();
+  for (auto &e : failed)
+    if (e) std::rethrow_exception(e);
+}
 void Library::Ring2Field(int32_t size, intType *inArr, intType *outputArr) const {
-  truncation->ring_to_field(size, inArr, outputArr, bitlength, field_mod);
+  split_over_threads(*this, size, inArr, outputArr, [this](Truncation &t, int32_t n, intType *in, intType *out) {
+    t.ring_to_field(n, in, out, bitlength, field_mod);
+  });
 }
 void Library::Field2Ring(int32_t size, intType *inArr, intType *outputArr) const {
-  truncation->field_to_ring(size, inArr, outputArr, field_mod, bitlength);
+  split_over_threads(*this, size, inArr, outputArr, [this](Truncation &t, int32_t n, intType *in, intType *out) {
+    t.field_to_ring(n, in, out, field_mod, bitlength);
+  });
 }
 void Library::Field2Ring_with_Truncate(int32_t size, intType *inArr, intType *outputArr) const {
-  truncation->field_to_ring_with_truncate(size, inArr, outputArr, field_mod, bitlength, kScale);
+  split_over_threads(*this, size, inArr, outputArr, [this](Truncation &t, int32_t n, intType *in, intType *out) {
+    t.field_to_ring_with_truncate(n, in, out, field_mod, bitlength, kScale);
+  });
 }
 
 // :567-600: ring -> field, SIMD product with the model's scale vector, field -> ring with the free truncation

@@ -2,6 +2,7 @@
 // like the reference; blocks, corrections and the wire cross PCIe once each.
 #include "mm_gemini/silent_ot.h"
 
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 
@@ -36,11 +37,23 @@ uint64_t gids(int64_t n) {
 }
 }  // namespace
 
+void SilentOT::fresh_seed(uint64_t seed[2]) {
+  if (seeded_) {
+    seed[0] = prg_(), seed[1] = prg_();
+    return;
+  }
+  std::FILE *f = std::fopen("/dev/urandom", "rb");
+  const bool ok = f && std::fread(seed, 8, 2, f) == 2;
+  if (f) std::fclose(f);
+  if (!ok) throw std::runtime_error("SilentOT: cannot read /dev/urandom");
+}
+
 void SilentOT::send(uint64_t *data0, const uint64_t *corr, int64_t n, int l, uint64_t p) {
   if (n <= 0) return;
   std::vector<Block> rcm(n);
   ferret_->send_ot_rcm_cc(rcm.data(), n);                      // silent_ot.h:89 / :131
-  const uint64_t seed[2] = {prg_(), prg_()};
+  uint64_t seed[2];
+  fresh_seed(seed);
   io_->send_data(seed, 16);                                    // :91-95
   const Block dl = ferret_->Delta();
   const uint64_t delta[2] = {dl.lo, dl.hi};

@@ -12,6 +12,7 @@ Same method names and argument meaning as the reference; ``send_cot`` .. ``recv_
 ``sci::OT<T>`` dispatches to them (SCI/src/OT/ot.h:80-93), so an object of this class is a ``cot`` for
 ``Truncation`` / ``AuxProtocols``.  ``IdealFerret`` and ``LoopbackIO`` are in-process test doubles.
 """
+import os
 import ctypes as C
 import queue
 
@@ -78,7 +79,9 @@ class SilentOT:
     def __init__(self, ferret, io, device=0, prg_seed=None):
         self.ferret, self.io, self.device = ferret, io, device
         self.lib = L.load_library()
-        self._prg = np.random.default_rng(prg_seed)
+        # the MITCCRH start point S travels in the clear and must be unpredictable (silent_ot.h:91-95 draws it
+        # from emp's AES-based PRG): the OS generator per call; a seeded stream only when a test asks for one
+        self._prg = None if prg_seed is None else np.random.default_rng(prg_seed)
         self.gid = 0          # MITCCRH's key counter: runs on across calls, setS does not reset it
         self.on_device = True  # results are CUDA tensors; corr / b may be CUDA tensors or numpy arrays
 
@@ -105,8 +108,11 @@ class SilentOT:
     def _send(self, corr, length, l, p):
         import torch
         rcm = self._dev(self.ferret.send_ot_rcm_cc(length), np.uint64)            # silent_ot.h:89 / :131
-        seed = self._prg.integers(0, 1 << 63, size=2, dtype=np.uint64) * np.uint64(2) + \
-            self._prg.integers(0, 2, size=2, dtype=np.uint64)
+        if self._prg is None:
+            seed = np.frombuffer(os.urandom(16), dtype=np.uint64).copy()
+        else:
+            seed = self._prg.integers(0, 1 << 63, size=2, dtype=np.uint64) * np.uint64(2) + \
+                self._prg.integers(0, 2, size=2, dtype=np.uint64)
         self.io.send_block(seed)                                                  # :91-95
         dev = f"cuda:{self.device}"
         corr_d = self._dev(corr, np.uint64)

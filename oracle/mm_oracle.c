@@ -331,6 +331,8 @@ void mmo_ctx_destroy(mmo_ctx *c) {
 static void fwd(const mmo_ctx *c, size_t l, uint64_t *a) {
   mmo_ntt_forward_fast(a, c->N, c->q[l], c->psi_rev[l], c->psi_rev_sh[l]);
 }
+static void fwd_any(const mmo_ctx *c, size_t l, uint64_t *a);  /* fwd / inv, or their AVX-512 restatement when */
+static void inv_any(const mmo_ctx *c, size_t l, uint64_t *a);  /* mmo_set_vector_isa(1) is in force: same bits  */
 static void inv(const mmo_ctx *c, size_t l, uint64_t *a) {
   mmo_ntt_inverse_fast(a, c->N, c->q[l], c->ipsi_rev[l], c->ipsi_rev_sh[l]);
 }
@@ -351,14 +353,14 @@ void mmo_multiply_plain(const mmo_ctx *c, int lv, const uint64_t *ct, const uint
   size_t Ll = mmo_level_limbs(c, lv), N = c->N;
   uint64_t *p = (uint64_t *)malloc(Ll * N * 8), *tmp = (uint64_t *)malloc(N * 8);
   mmo_plain_lift(c, lv, pt, len, p);
-  for (size_t l = 0; l < Ll; l++) fwd(c, l, p + l * N);
+  for (size_t l = 0; l < Ll; l++) fwd_any(c, l, p + l * N);
   for (size_t k = 0; k < 2; k++)
     for (size_t l = 0; l < Ll; l++) {
       const uint64_t *src = ct + (k * Ll + l) * N;
       memcpy(tmp, src, N * 8);
-      fwd(c, l, tmp);
+      fwd_any(c, l, tmp);
       mmo_dyadic_mul(tmp, p + l * N, tmp, N, c->q[l]);
-      inv(c, l, tmp);
+      inv_any(c, l, tmp);
       memcpy(out + (k * Ll + l) * N, tmp, N * 8);
     }
   free(p); free(tmp);
@@ -813,15 +815,33 @@ void mmo_bole_cross_term(uint64_t *out, const uint64_t *x, const uint64_t *y, si
 }
 
 /* ------------------------------------------------- CPU baseline batches */
+/* vector = 1: the AVX-512 restatement (mm_oracle_avx512.c) where the host has it; the results are the same bits */
+static int g_vector = 0;
+int mmo_set_vector_isa(int on) {
+  g_vector = on && mmo_have_avx512();
+  return g_vector;
+}
+static void fwd_any(const mmo_ctx *c, size_t l, uint64_t *a) {
+  if (g_vector) mmo_ntt_forward_avx512(a, c->N, c->q[l], c->psi_rev[l], c->psi_rev_sh[l]);
+  else fwd(c, l, a);
+}
+static void inv_any(const mmo_ctx *c, size_t l, uint64_t *a) {
+  if (g_vector) {
+    uint64_t ninv = mmo_invmod((uint64_t)c->N % c->q[l], c->q[l]);
+    mmo_ntt_inverse_avx512(a, c->N, c->q[l], c->ipsi_rev[l], c->ipsi_rev_sh[l], ninv, mmo_shoup(ninv, c->q[l]));
+  } else {
+    inv(c, l, a);
+  }
+}
 void mmo_ntt_forward_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads) {
   long total = (long)(n_polys * limbs);
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (long b = 0; b < total; b++) fwd(c, (size_t)b % limbs, polys + (size_t)b * c->N);
+  for (long b = 0; b < total; b++) fwd_any(c, (size_t)b % limbs, polys + (size_t)b * c->N);
 }
 void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads) {
   long total = (long)(n_polys * limbs);
 #pragma omp parallel for num_threads(threads) schedule(static)
-  for (long b = 0; b < total; b++) inv(c, (size_t)b % limbs, polys + (size_t)b * c->N);
+  for (long b = 0; b < total; b++) inv_any(c, (size_t)b % limbs, polys + (size_t)b * c->N);
 }
 
 /* conv2DOneFilter for every filter (hom_conv2d_ss.cc:563-619, :679-690) in the reference's own

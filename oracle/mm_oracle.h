@@ -224,6 +224,14 @@ long mmo_fc_encode_weights(long N, uint64_t t, const uint64_t *W, long nrows, lo
                            uint64_t *polys);
 
 /* ---- timed CPU baseline helpers (bench.py cpu_baseline leg): OpenMP over independent polys */
+/* AVX-512 restatement of the two lazy transforms (mm_oracle_avx512.c), same bits as the *_fast functions;
+ * mmo_set_vector_isa(1) makes the batch functions below use it where the host has AVX-512F/DQ (returns what is
+ * in force) */
+int mmo_have_avx512(void);
+int mmo_set_vector_isa(int on);
+void mmo_ntt_forward_avx512(uint64_t *a, size_t N, uint64_t q, const uint64_t *psi_rev, const uint64_t *psi_rev_sh);
+void mmo_ntt_inverse_avx512(uint64_t *a, size_t N, uint64_t q, const uint64_t *ipsi_rev, const uint64_t *ipsi_rev_sh,
+                            uint64_t ninv, uint64_t ninv_sh);
 void mmo_ntt_forward_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
 void mmo_ntt_inverse_batch(const mmo_ctx *c, uint64_t *polys, size_t n_polys, size_t limbs, int threads);
 void mmo_conv_mac_reference(const mmo_ctx *c, const uint64_t *image, const uint64_t *filters, size_t M,

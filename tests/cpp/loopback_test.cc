@@ -246,6 +246,64 @@ int main(int argc, char **argv) {
     EXPECT(n % 8 != 0 || cio.first->counter == expect_bytes, "wire bytes: seed + 4 B (mod p), 32 b and 32 b per element");
   }
 
+  // ---- Ring2Field / Field2Ring / Field2Ring_with_Truncate split over three worker threads per party, each with its
+  // own channel and COT, the odd one with the roles swapped (library_fixed_uniform_cheetah.cpp:492-565,
+  // library_fixed_uniform.cpp:1540-1554): party 2 is the COT sender of thread 1 ----------------------------------
+  {
+    const int nt = 3, sz = 1003, ks = 12;  // chunks of 40, 40 and 923 elements
+    std::vector<std::shared_ptr<mm::IdealFerret::Mailbox>> boxes;
+    std::vector<std::pair<std::unique_ptr<mm::LoopbackIO>, std::unique_ptr<mm::LoopbackIO>>> ios;
+    std::vector<std::unique_ptr<mm::IdealFerret>> ferrets;
+    std::vector<std::unique_ptr<mm::SilentOT>> ots;
+    std::vector<std::unique_ptr<mm::Truncation>> truncs;
+    mm::Library lib[2];
+    for (int q = 0; q < 2; ++q) {
+      lib[q].party = q + 1, lib[q].bitlength = bw, lib[q].kScale = ks, lib[q].prime_mod = 1ULL << bw;
+      lib[q].field_mod = prime;
+    }
+    for (int i = 0; i < nt; ++i) {
+      boxes.push_back(std::make_shared<mm::IdealFerret::Mailbox>());
+      ios.push_back(mm::LoopbackIO::MakePair());
+      for (int q = 0; q < 2; ++q) {
+        ferrets.emplace_back(new mm::IdealFerret(boxes[i], 100 + 2 * i + q));
+        ots.emplace_back(new mm::SilentOT(ferrets.back().get(), (q ? ios[i].second : ios[i].first).get(), 200 + 2 * i + q));
+        const int role = (i & 1) ? 3 - (q + 1) : q + 1;
+        truncs.emplace_back(new mm::Truncation(role, ots.back().get()));
+        lib[q].truncationArr.push_back(truncs.back().get());
+      }
+    }
+    std::vector<int64_t> v(sz);
+    std::vector<u64> s[2], f[2], r[2], tr[2];
+    for (int q = 0; q < 2; ++q) s[q].resize(sz), f[q].resize(sz), r[q].resize(sz), tr[q].resize(sz);
+    for (int i = 0; i < sz; ++i) {
+      v[i] = (int64_t)(rng() % (1ULL << (bw - 2))) - (1LL << (bw - 3));
+      s[0][i] = rng() & mask, s[1][i] = ((u64)v[i] - s[0][i]) & mask;
+    }
+    both(A, B, [&](Party &p) {
+      const int q = p.id - 1;
+      mm::Library::Bind(&lib[q]);
+      Ring2Field(sz, s[q].data(), f[q].data());
+      for (int i = 0; i < sz; ++i) f[q][i] %= prime;
+      Field2Ring(sz, f[q].data(), r[q].data());
+      Field2Ring_with_Truncate(sz, f[q].data(), tr[q].data());
+    });
+    bool r2f = true, f2r = true, trunc = true;
+    for (int i = 0; i < sz; ++i) {
+      r2f &= (f[0][i] + f[1][i]) % prime == (u64)((v[i] % (int64_t)prime + (int64_t)prime) % (int64_t)prime);
+      f2r &= to_signed(r[0][i] + r[1][i], bw) == v[i];
+      const int64_t err = to_signed(tr[0][i] + tr[1][i], bw) - (v[i] >> ks);
+      trunc &= err >= -1 && err <= 2;
+    }
+    EXPECT(r2f, "Ring2Field over three threads, roles swapped on the odd one: exact");
+    EXPECT(f2r, "Field2Ring over three threads, roles swapped on the odd one: exact");
+    EXPECT(trunc, "Field2Ring_with_Truncate over three threads: the value >> kScale up to the protocol's own rounding");
+    bool used = true, swapped = ios[1].second->counter > 0 && ios[1].first->counter == 0;
+    for (int i = 0; i < nt; ++i) used &= (ios[i].first->counter + ios[i].second->counter) > 0;
+    EXPECT(used, "every thread's channel carried its chunk");
+    EXPECT(swapped && ios[0].first->counter > 0 && ios[0].second->counter == 0,
+           "COT corrections flow from party 1 on even threads and from party 2 on the odd one");
+  }
+
   // ---- ReLU, multiplexer and B2A of the USE_CHEETAH build (relu-ring.h:216-313, aux-protocols.cpp:62-126) over two
   // COTs: once over the ideal COT, once over mm::SilentOT (device post-processing); the comparison stays ideal ----
   for (int variant = 0; variant < 2; ++variant) {

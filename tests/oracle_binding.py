@@ -114,6 +114,9 @@ def load():
         lib.mmo_cot_wire_bytes.restype = sz
         lib.mmo_cot_send.argtypes = [vp, vp, vp, u64, vp, sz, ci, u64, ci, vp, vp]
         lib.mmo_cot_recv.argtypes = [vp, vp, vp, u64, vp, sz, ci, u64, ci, vp]
+        lib.mmo_have_avx512.restype = ci
+        lib.mmo_set_vector_isa.argtypes = [ci]
+        lib.mmo_set_vector_isa.restype = ci
         lib.mmo_ntt_forward_batch.argtypes = [P, vp, sz, sz, ci]
         lib.mmo_ntt_inverse_batch.argtypes = [P, vp, sz, sz, ci]
         lib.mmo_conv_mac_reference.argtypes = [P, vp, vp, sz, sz, sz, vp, ci]

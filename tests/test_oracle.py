@@ -268,3 +268,31 @@ def test_modulo_mult_is_mulmod():
     a, b = splitmix64(SEED, 200), splitmix64(SEED + 1, 200)
     for x, y in zip(a, b):
         assert lib.mmo_modulo_mult(int(x), int(y) >> 20, P32) == (int(x) % P32) * (int(y) >> 20) % P32
+
+
+@pytest.mark.parametrize("N,bits", [(4096, (60, 49)), (8192, (60, 60, 60, 49))])
+def test_avx512_restatement_gives_the_same_bits(N, bits):
+    """oracle/mm_oracle_avx512.c (the CPU baseline's vector code) against the scalar lazy transforms it restates:
+    forward on lazy inputs in [0, 4q), inverse on [0, 2q), every limb, through the batch entry points"""
+    from tests.oracle_binding import load as load_oracle
+    lib = load_oracle()
+    if not lib.mmo_have_avx512():
+        pytest.skip("host without AVX-512F/DQ")
+    o = OracleCtx(N, bits, 0)
+    L = len(o.q)
+    qs = np.array(o.q, dtype=np.uint64)[None, :, None]
+    raw = splitmix64(0xA5, 3 * L * N).reshape(3, L, N)
+    for lazy, fn in ((4, lib.mmo_ntt_forward_batch), (2, lib.mmo_ntt_inverse_batch)):
+        a = raw % (qs * np.uint64(lazy))
+        a[0, :, :8] = qs[0] * np.uint64(lazy) - np.uint64(1)     # the top of the lazy range
+        a[1, :, -8:] = 0
+        want, got = a.copy(), a.copy()
+        try:
+            assert lib.mmo_set_vector_isa(0) == 0
+            fn(o.p, A(want), 3, L, 1)
+            assert lib.mmo_set_vector_isa(1) == 1
+            fn(o.p, A(got), 3, L, 2)
+        finally:
+            lib.mmo_set_vector_isa(0)
+        assert np.array_equal(got, want)
+        assert not np.array_equal(got, a)

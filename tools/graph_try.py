@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, openmm_amd
 from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
 t, N = 1 << 37, 4096
