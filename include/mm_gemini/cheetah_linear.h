@@ -43,6 +43,11 @@ class CheetahLinear {
   void release_device_buffers() const;
   void fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
           Tensor<uint64_t> &out_vec_share) const;
+  // the same with the weights as the layer adapter holds them: [meta.weight_shape.cols()][meta.weight_shape.rows()]
+  // row-major (input x output), any 64-bit values; transposed and reduced into the ring on the device instead of in
+  // a strided host loop (library_fixed_uniform_cheetah.cpp:93-101).  ALICE only reads weights_in_out.
+  void fc_in_out(const Tensor<uint64_t> &input_vector, const uint64_t *weights_in_out, const FCMeta &meta,
+                 Tensor<uint64_t> &out_vec_share) const;
   void bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &scale_vector, const BNMeta &meta,
           Tensor<uint64_t> &out_vector) const;
   void BOLE(const Tensor<uint64_t> &input_x_vector, const Tensor<uint64_t> &input_y_vector, const BNMeta &meta,
@@ -72,6 +77,8 @@ class CheetahLinear {
   uint64_t field_mod() const { return field_mod_; }
 
  private:
+  void fc_any(const Tensor<uint64_t> &input_vector, const uint64_t *wd, bool in_out, const FCMeta &meta,
+              Tensor<uint64_t> &out_vec_share) const;
   struct Impl;
   int party_;
   mm::IOChannel *io_;

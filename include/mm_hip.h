@@ -227,6 +227,13 @@ int mmh_batch_decode_noalloc_max(const mmh_ctx *ctx, size_t *max_n);
  * words 14-15) keyed by the caller feeds the same three distributions.  Streams are not
  * comparable with SEAL's, only the distributions are; parity tests inject explicit randomness.
  * ===================================================================================== */
+/* A fresh symmetric ciphertext is (c0, c1 = a) with `a` uniform: the reference ships it as c0 plus the PRNG seed
+ * of `a` (seal::Serializable<Ciphertext> from encrypt_symmetric, saved by send_ciphertext, cheetah-api.cpp:11-29 on
+ * the output of encryptImage :401-406) and the receiver expands the seed again.  These two move the halves of
+ * [n][2][limbs(lv)][N] apart and back together; the expansion itself is mmh_sample_uniform with the shipped key. */
+int mmh_ct_split_c0(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, size_t n, uint64_t *d_c0, void *stream);
+int mmh_ct_join(const mmh_ctx *ctx, int lv, const uint64_t *d_c0, const uint64_t *d_c1, size_t n, uint64_t *d_cts,
+                void *stream);
 /* raw keystream as little-endian 64-bit words, starting at block `counter0` */
 int mmh_chacha20_words(const uint32_t key[8], uint64_t stream_id, uint64_t counter0, uint64_t *d_out,
                        size_t n_words, void *stream);
@@ -333,6 +340,15 @@ int mmh_conv_server_prepared(const mmh_conv_plan *plan, const uint64_t *d_in_cts
                              const mmh_conv_filters *filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                              const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                              uint64_t *d_out_share, void *stream);
+/* Compact wire form of conv2DSS's result ciphertexts [n_out][2][N] (last level).  The reference sends them through
+ * seal::Ciphertext::save (cheetah-api.cpp:11-29, :443-444), whose compression squeezes out what
+ * truncate_for_decryption (hom_conv2d_ss.cc:418-436) and remove_unused_coeffs (:800-851) zeroed; this pair does it
+ * by construction: per ciphertext the N coefficients of c1 without their cleared low bits, then the kept
+ * coefficients of c0 likewise, as two bit streams padded to whole words (words_per_ct in all, the same for every
+ * ciphertext of the plan).  unpack(pack(ct)) == ct for every ciphertext the server calls produce. */
+int mmh_conv_result_packed_words(const mmh_conv_plan *plan, size_t *words_per_ct);
+int mmh_conv_result_pack(const mmh_conv_plan *plan, const uint64_t *d_cts, uint64_t *d_packed, void *stream);
+int mmh_conv_result_unpack(const mmh_conv_plan *plan, const uint64_t *d_packed, uint64_t *d_cts, void *stream);
 /* HomConv2DSS::decryptToTensor (hom_conv2d_ss.cc:853-941): d_sk_ntt at the last level [1][N] */
 int mmh_conv_decrypt(const mmh_conv_plan *plan, const uint64_t *d_sk_ntt, const uint64_t *d_cts,
                      uint64_t *d_out, void *stream);

@@ -690,6 +690,32 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
 }
 }  // namespace mmh
 
+// Fresh symmetric ciphertexts travel as c0 plus the seed their c1 was expanded from (seal::Serializable<Ciphertext>
+// of encrypt_symmetric, cheetah-api.cpp:11-29 on :401-406): the two halves of [n][2][limbs][N] apart and back together.
+extern "C" int mmh_ct_split_c0(const mmh_ctx *ctx, int lv, const uint64_t *d_cts, size_t n, uint64_t *d_c0,
+                               void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts && d_c0, MMH_ERR_NULL_POINTER);
+  const size_t half = (size_t)ctx->bfv.lv[lv].limbs * ctx->N * 8;
+  MMH_HIP(hipMemcpy2DAsync(d_c0, half, d_cts, 2 * half, half, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMH_OK;
+}
+extern "C" int mmh_ct_join(const mmh_ctx *ctx, int lv, const uint64_t *d_c0, const uint64_t *d_c1, size_t n,
+                           uint64_t *d_cts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  CHECK_RC(check_bfv(ctx, lv));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_cts && d_c0 && d_c1, MMH_ERR_NULL_POINTER);
+  const size_t half = (size_t)ctx->bfv.lv[lv].limbs * ctx->N * 8;
+  hipStream_t s = (hipStream_t)stream;
+  MMH_HIP(hipMemcpy2DAsync(d_cts, 2 * half, d_c0, half, half, n, hipMemcpyDeviceToDevice, s));
+  MMH_HIP(hipMemcpy2DAsync(reinterpret_cast<char *>(d_cts) + half, 2 * half, d_c1, half, half, n,
+                           hipMemcpyDeviceToDevice, s));
+  return MMH_OK;
+}
+
 extern "C" int mmh_batch_encode(const mmh_ctx *ctx, const uint64_t *d_vals, size_t n, uint64_t *d_pts,
                                 void *stream) {
   MMH_DEVICE_SCOPE(ctx);

@@ -47,6 +47,12 @@ struct mmh_conv_plan {
   uint32_t *d_tgt_slice = nullptr;       // [n_targets] spatial window the target belongs to
   uint8_t *d_keep = nullptr;             // [n_spatial][N] coefficients that survive remove_unused_coeffs
   int *d_share_dst = nullptr;            // [n_spatial][N] offset of a target coefficient in the result plane, else -1
+  // compact wire form of the result ciphertexts (mmh_conv_result_pack): per spatial window the kept coefficients of
+  // c0 in ascending order, and where a coefficient sits in that list
+  uint32_t *d_kept_idx = nullptr;        // [sum of kept] coefficient index
+  uint32_t *d_kept_off = nullptr;        // [n_spatial + 1] first entry of a window's list
+  int *d_kept_rank = nullptr;            // [n_spatial][N] position in the window's list, else -1
+  size_t max_kept = 0;                   // longest list
   // 1x1 filters with few channels per polynomial: multiply-accumulate as a mod-q matrix product over
   // channels (pointwise_mac below) instead of transforming M*Cs sparse filter polynomials
   bool direct_capable = false;           // tables below are built
@@ -943,6 +949,23 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     p->direct_fresh = !never && (always || t_direct < t_fresh);
     p->direct_prepared = !never && (always || t_direct < t_prepared);
   }
+  std::vector<u32> kept_idx, kept_off(p->n_spatial + 1, 0);
+  std::vector<int> kept_rank(p->n_spatial * (size_t)N, -1);
+  for (size_t s_ = 0; s_ < p->n_spatial; ++s_) {
+    kept_off[s_] = (u32)kept_idx.size();
+    for (long i = 0; i < N; ++i)
+      if (keep[s_ * N + i]) {
+        kept_rank[s_ * N + i] = (int)(kept_idx.size() - kept_off[s_]);
+        kept_idx.push_back((u32)i);
+      }
+    p->max_kept = std::max(p->max_kept, kept_idx.size() - kept_off[s_]);
+  }
+  kept_off[p->n_spatial] = (u32)kept_idx.size();
+  if ((rc = upload_vec(p, kept_idx, &p->d_kept_idx)) || (rc = upload_vec(p, kept_off, &p->d_kept_off)) ||
+      (rc = upload_vec(p, kept_rank, &p->d_kept_rank))) {
+    mmh_conv_plan_destroy(p);
+    return rc;
+  }
   if ((rc = upload_vec(p, wins, &p->d_windows)) || (rc = upload_vec(p, coef, &p->d_tgt_coef)) ||
       (rc = upload_vec(p, dst, &p->d_tgt_dst)) || (rc = upload_vec(p, slice, &p->d_tgt_slice)) ||
       (rc = upload_vec(p, keep, &p->d_keep)) || (rc = upload_vec(p, share_dst, &p->d_share_dst))) {
@@ -1237,6 +1260,103 @@ extern "C" int mmh_conv_server_prepared(const mmh_conv_plan *p, const uint64_t *
   MMH_REQUIRE(filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                           d_out_share, stream, nullptr, nullptr, filters);
+}
+
+// ---------------------------------------------------------------- compact wire form of the results
+// A result ciphertext of conv2DSS holds far fewer bits than its [2][N] words: truncate_for_decryption cleared the
+// low bits of every coefficient (hom_conv2d_ss.cc:418-436) and remove_unused_coeffs zeroed c0 outside the kept
+// coefficients (:800-851).  The reference leaves the squeezing to SEAL's serializer (Ciphertext::save compresses,
+// cheetah-api.cpp:11-29); here the two facts are used directly: per ciphertext N values of c1 with the cleared
+// low bits dropped, then the kept coefficients of c0 likewise, each section a bit stream padded to whole words.
+namespace mmh {
+struct PackGeom {
+  int tz1, b1, tz0, b0;        // cleared low bits and the width that is left, c1 and c0
+  size_t words1, words0;       // words of the two sections
+  __host__ __device__ size_t words() const { return words1 + words0; }
+};
+static PackGeom pack_geom(const mmh_conv_plan *p) {
+  const mmh_ctx *ctx = p->ctx;
+  PackGeom g;
+  const int qbits = 64 - __builtin_clzll(ctx->q[0]);
+  g.tz1 = ctx->bfv.mask1 ? __builtin_ctzll(ctx->bfv.mask1) : 0, g.tz0 = ctx->bfv.mask0 ? __builtin_ctzll(ctx->bfv.mask0) : 0;
+  g.b1 = qbits - g.tz1, g.b0 = qbits - g.tz0;
+  g.words1 = (ctx->N * (size_t)g.b1 + 63) / 64, g.words0 = (p->max_kept * (size_t)g.b0 + 63) / 64;
+  return g;
+}
+// one output word per thread: the values whose bits [i*b, i*b + b) overlap bits [64w, 64w + 64) of the section
+template <class Value>
+__device__ __forceinline__ u64 pack_word(size_t w, int b, size_t count, Value value) {
+  const size_t lo = w * 64, hi = lo + 64;
+  u64 out = 0;
+  for (size_t i = lo / b; i * b < hi && i < count; ++i) {
+    const u64 v = value(i);
+    const long long shift = (long long)(i * b) - (long long)lo;  // where the value's bit 0 lands in this word
+    out |= shift >= 0 ? v << shift : v >> -shift;
+  }
+  return out;
+}
+__device__ __forceinline__ u64 unpack_value(const u64 *__restrict__ sec, size_t i, int b) {
+  const size_t bit = i * b, w = bit / 64;
+  const int off = (int)(bit % 64);
+  u64 v = sec[w] >> off;
+  if (off + b > 64) v |= sec[w + 1] << (64 - off);
+  return b == 64 ? v : v & ((u64(1) << b) - 1);
+}
+__global__ __launch_bounds__(256) void result_pack_kernel(const u64 *__restrict__ cts, u64 *__restrict__ packed,
+                                                          size_t n_out, size_t S, int logN, PackGeom g,
+                                                          const u32 *__restrict__ kept_idx,
+                                                          const u32 *__restrict__ kept_off) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, per = g.words();
+  if (idx >= n_out * per) return;
+  const size_t k = idx / per, w = idx % per, N = size_t(1) << logN;
+  const u64 *c0 = cts + ((k * 2) << logN), *c1 = c0 + N;
+  if (w < g.words1) {
+    packed[idx] = pack_word(w, g.b1, N, [&](size_t i) { return c1[i] >> g.tz1; });
+  } else {
+    const u32 first = kept_off[k % S], count = kept_off[k % S + 1] - first;
+    packed[idx] = pack_word(w - g.words1, g.b0, count, [&](size_t i) { return c0[kept_idx[first + i]] >> g.tz0; });
+  }
+}
+__global__ __launch_bounds__(256) void result_unpack_kernel(const u64 *__restrict__ packed, u64 *__restrict__ cts,
+                                                            size_t n_out, size_t S, int logN, PackGeom g,
+                                                            const int *__restrict__ kept_rank) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n_out][2][N]
+  if (idx >= (n_out * 2) << logN) return;
+  const size_t k = idx >> (logN + 1), i = idx & ((size_t(1) << logN) - 1);
+  const bool is_c1 = (idx >> logN) & 1;
+  const u64 *sec = packed + k * g.words();
+  if (is_c1) {
+    cts[idx] = unpack_value(sec, i, g.b1) << g.tz1;
+  } else {
+    const int r = kept_rank[((k % S) << logN) + i];
+    cts[idx] = r < 0 ? 0 : unpack_value(sec + g.words1, (size_t)r, g.b0) << g.tz0;
+  }
+}
+}  // namespace mmh
+
+extern "C" int mmh_conv_result_packed_words(const mmh_conv_plan *p, size_t *words_per_ct) {
+  MMH_REQUIRE(p && words_per_ct, MMH_ERR_NULL_POINTER);
+  *words_per_ct = pack_geom(p).words();
+  return MMH_OK;
+}
+extern "C" int mmh_conv_result_pack(const mmh_conv_plan *p, const uint64_t *d_cts, uint64_t *d_packed, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
+  MMH_REQUIRE(p && d_cts && d_packed, MMH_ERR_NULL_POINTER);
+  const PackGeom g = pack_geom(p);
+  hipLaunchKernelGGL(result_pack_kernel, dim3(nblk(p->n_out * g.words())), dim3(256), 0, (hipStream_t)stream, d_cts,
+                     d_packed, p->n_out, p->n_spatial, p->ctx->logN, g, p->d_kept_idx, p->d_kept_off);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+extern "C" int mmh_conv_result_unpack(const mmh_conv_plan *p, const uint64_t *d_packed, uint64_t *d_cts,
+                                      void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
+  MMH_REQUIRE(p && d_cts && d_packed, MMH_ERR_NULL_POINTER);
+  const PackGeom g = pack_geom(p);
+  hipLaunchKernelGGL(result_unpack_kernel, dim3(nblk((p->n_out * 2) << p->ctx->logN)), dim3(256), 0,
+                     (hipStream_t)stream, d_packed, d_cts, p->n_out, p->n_spatial, p->ctx->logN, g, p->d_kept_rank);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
 }
 
 extern "C" int mmh_conv_decrypt(const mmh_conv_plan *p, const uint64_t *d_sk_ntt, const uint64_t *d_cts,

@@ -294,6 +294,29 @@ class HomConv2DSS:
                                               L._stream_ptr()))
         return out
 
+    # compact wire form of the result ciphertexts (what seal::Ciphertext::save's compression does for the
+    # reference, cheetah-api.cpp:11-29): [n_out][words_per_ct] words, unpack(pack(cts)) == cts
+    def packedWords(self, meta):
+        n = C.c_size_t()
+        L.check(self.ctx.lib.mmh_conv_result_packed_words(self.plan(meta).handle, C.byref(n)))
+        return n.value
+
+    def packResult(self, enc_tensor, meta):
+        p = self.plan(meta)
+        self._need(tuple(enc_tensor.shape) == (p.n_out, 2, 1, self.ctx.N), 3, "packResult: ciphertext shape")
+        out = self.ctx._empty(p.n_out, self.packedWords(meta))
+        L.check(self.ctx.lib.mmh_conv_result_pack(p.handle, L.dptr(enc_tensor.contiguous()), L.dptr(out),
+                                                  L._stream_ptr()))
+        return out
+
+    def unpackResult(self, packed, meta):
+        p = self.plan(meta)
+        self._need(tuple(packed.shape) == (p.n_out, self.packedWords(meta)), 3, "unpackResult: packed shape")
+        out = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
+        L.check(self.ctx.lib.mmh_conv_result_unpack(p.handle, L.dptr(packed.contiguous()), L.dptr(out),
+                                                    L._stream_ptr()))
+        return out
+
     # idealFunctionality (hom_conv2d_ss.cc:975-1012; Tensor::Conv2D tensor.h:274-362), mod 2^k only
     def idealFunctionality(self, in_tensor, filters, meta):
         import torch

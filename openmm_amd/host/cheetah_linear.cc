@@ -286,6 +286,48 @@ struct CheetahLinear::Impl {
     return d;
   }
 
+  // ---- fresh symmetric ciphertexts: c0 and the 32-byte seed of c1 = a on the wire, as seal::Serializable<Ciphertext>
+  // (encrypt_symmetric(...).save(), cheetah-api.cpp:11-29 on :401-406); the receiver expands the seed again ----
+  struct Fresh {
+    Dev a;
+    uint32_t seed[8];
+  };
+  Fresh fresh(const mmh_ctx *c, size_t n) const {  // `a` for n ciphertexts at the first level, from a public seed
+    Fresh f;
+    FILE *r = std::fopen("/dev/urandom", "rb");
+    const bool ok = r && std::fread(f.seed, 1, sizeof(f.seed), r) == sizeof(f.seed);
+    if (r) std::fclose(r);
+    if (!ok) throw std::runtime_error("CheetahLinear: cannot draw a ciphertext seed");
+    f.a = mk(n * L * N);
+    must(mmh_sample_uniform(c, 0, f.seed, 0, f.a.p, n, stream), "sample_uniform");
+    return f;
+  }
+  void send_fresh(const mmh_ctx *c, const Dev &cts, const Fresh &f, size_t n) const {  // drains the stream
+    Dev c0 = mk(n * L * N);
+    must(mmh_ct_split_c0(c, 0, cts.p, n, c0.p, stream), "split");
+    stage_cts(c0, n * L * N);
+    sync();
+    uint32_t cnt = (uint32_t)n;
+    io->send_data(&cnt, sizeof(cnt));
+    io->send_data(f.seed, sizeof(f.seed));
+    io->send_data(staging.p, n * L * N * 8);
+    io->flush();
+  }
+  Dev recv_fresh(const mmh_ctx *c, size_t expect) const {  // waits for the peer; the rest is enqueued
+    uint32_t n = 0, seed[8];
+    io->recv_data(&n, sizeof(n));
+    if (n != expect) throw std::runtime_error("CheetahLinear: ciphertext count mismatch");
+    io->recv_data(seed, sizeof(seed));
+    const size_t half = (size_t)n * L * N;
+    uint64_t *host = stage(half);
+    io->recv_data(host, half * 8);
+    Dev c0 = mk(half), a = mk(half), cts = mk(2 * half);
+    up(c0, host, half);
+    must(mmh_sample_uniform(c, 0, seed, 0, a.p, n, stream), "sample_uniform");
+    must(mmh_ct_join(c, 0, c0.p, a.p, n, cts.p, stream), "join");
+    return cts;
+  }
+
   // conv2DOneFilter's zero-filter verdict (hom_conv2d_ss.cc:573-580), written by the layer call on the device
   uint32_t *zero_flag_host() const {
     if (!flag_host) {
@@ -301,13 +343,17 @@ struct CheetahLinear::Impl {
   void conv_core(int party, const ConvMeta &meta, mmh_conv_plan *plan, size_t n_in, size_t n_out, const Dev &d_img,
                  const Dev *d_filters, const Dev &d_out, const std::function<void()> &before_wait) const {
     if (party == kBob) {
-      Dev a = uniform(ring.ctx, 0, n_in), e = noise(n_in), cts = mk(n_in * 2 * L * N);
-      must(mmh_conv_encrypt_image(plan, ring.sk.p, d_img.p, a.p, (const int64_t *)e.p, cts.p, stream),
+      Fresh f = fresh(ring.ctx, n_in);
+      Dev e = noise(n_in), cts = mk(n_in * 2 * L * N);
+      must(mmh_conv_encrypt_image(plan, ring.sk.p, d_img.p, f.a.p, (const int64_t *)e.p, cts.p, stream),
            "CheetahLinear::conv2d encryptImage");
-      stage_cts(cts, n_in * 2 * L * N);
-      sync();
-      send_staged(n_in, 2 * L * N);
-      Dev res = recv_cts(n_out, 2 * N);
+      send_fresh(ring.ctx, cts, f, n_in);
+      // the result ciphertexts arrive in their compact form (mmh_conv_result_pack: the cleared low bits and the
+      // removed coefficients of c0 are not on the wire, as after seal::Ciphertext::save's compression)
+      size_t packed_words = 0;
+      must(mmh_conv_result_packed_words(plan, &packed_words), "CheetahLinear::conv2d");
+      Dev wire = recv_cts(n_out, packed_words), res = mk(n_out * 2 * N);
+      must(mmh_conv_result_unpack(plan, wire.p, res.p, stream), "CheetahLinear::conv2d unpack");
       must(mmh_conv_decrypt(plan, ring.sk_last.p, res.p, d_out.p, stream), "CheetahLinear::conv2d decryptToTensor");
       before_wait();
       sync();
@@ -315,7 +361,7 @@ struct CheetahLinear::Impl {
       // randomness and the flag are enqueued before the (blocking) receive, so they run while the client encrypts
       Dev u = ternary(n_out), e1 = noise(n_out), mask = uniform(ring.ctx, 1, n_out);
       Dev out_cts = mk(n_out * 2 * N), flag = mk(1);
-      Dev cts = recv_cts(n_in, 2 * L * N);
+      Dev cts = recv_fresh(ring.ctx, n_in);
       // encodeImage + encodeFilters + conv2DSS (cheetah-api.cpp:401-445) in one device call
       must(mmh_conv_server_tensors(plan, cts.p, meta.is_shared_input ? d_img.p : nullptr, d_filters->p, ring.pk_last.p,
                                    (const int64_t *)u.p, (const int64_t *)e1.p, mask.p, out_cts.p, d_out.p,
@@ -323,11 +369,15 @@ struct CheetahLinear::Impl {
            "CheetahLinear::conv2d conv2DSS:");
       uint32_t *verdict = zero_flag_host();
       must(mmh_memcpy_d2h(verdict, flag.p, 4, stream), "d2h");
-      stage_cts(out_cts, n_out * 2 * N);
+      size_t packed_words = 0;
+      must(mmh_conv_result_packed_words(plan, &packed_words), "CheetahLinear::conv2d");
+      Dev wire = mk(n_out * packed_words);
+      must(mmh_conv_result_pack(plan, out_cts.p, wire.p, stream), "CheetahLinear::conv2d pack");
+      stage_cts(wire, n_out * packed_words);
       before_wait();
       sync();
       if (*verdict) throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
-      send_staged(n_out, 2 * N);
+      send_staged(n_out, packed_words);
     }
   }
 };
@@ -433,9 +483,19 @@ void CheetahLinear::conv2d_nhwc(const uint64_t *input_nhwc, const uint64_t *filt
 
 void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
                        Tensor<uint64_t> &out_vec_share) const {
-  if (!input_vector.shape().IsSameSize(meta.input_shape)) throw std::invalid_argument("CheetahLinear::fc input shape mismatch");
   if (party_ == kAlice && !weight_matrix.shape().IsSameSize(meta.weight_shape))
     throw std::invalid_argument("CheetahLinear::fc weight shape mismatch");
+  fc_any(input_vector, party_ == kAlice ? weight_matrix.data() : nullptr, false, meta, out_vec_share);
+}
+void CheetahLinear::fc_in_out(const Tensor<uint64_t> &input_vector, const uint64_t *weights_in_out, const FCMeta &meta,
+                              Tensor<uint64_t> &out_vec_share) const {
+  if (party_ == kAlice && !weights_in_out) throw std::invalid_argument("CheetahLinear::fc weights missing");
+  fc_any(input_vector, weights_in_out, true, meta, out_vec_share);
+}
+// wd: rows x cols row-major, or (in_out) cols x rows row-major with unreduced entries
+void CheetahLinear::fc_any(const Tensor<uint64_t> &input_vector, const uint64_t *wd, bool in_out, const FCMeta &meta,
+                           Tensor<uint64_t> &out_vec_share) const {
+  if (!input_vector.shape().IsSameSize(meta.input_shape)) throw std::invalid_argument("CheetahLinear::fc input shape mismatch");
   TensorShape out_shape({meta.weight_shape.dim_size(0)});
   if (!out_vec_share.shape().IsSameSize(out_shape)) out_vec_share.Reshape(out_shape);
   const Impl &I = *impl_;
@@ -449,33 +509,37 @@ void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64
   Dev vec = I.mk(cols);
   I.up(vec, input_vector.data(), cols);
   if (party_ == kBob) {
-    Dev a = I.uniform(I.ring.ctx, 0, n_in), e = I.noise(n_in), cts = I.mk(n_in * 2 * L * N);
-    must(mmh_fc_encrypt_input(plan, I.ring.sk.p, vec.p, a.p, (const int64_t *)e.p, cts.p, I.stream),
+    Impl::Fresh f = I.fresh(I.ring.ctx, n_in);
+    Dev e = I.noise(n_in), cts = I.mk(n_in * 2 * L * N);
+    must(mmh_fc_encrypt_input(plan, I.ring.sk.p, vec.p, f.a.p, (const int64_t *)e.p, cts.p, I.stream),
          "CheetahLinear::fc encryptInputVector");
-    I.stage_cts(cts, n_in * 2 * L * N);
-    I.sync();
-    I.send_staged(n_in, 2 * L * N);
+    I.send_fresh(I.ring.ctx, cts, f, n_in);
     Dev res = I.recv_cts(n_out, 2 * N), out = I.mk(rows);
     must(mmh_fc_decrypt(plan, I.ring.sk_last.p, res.p, out.p, I.stream), "CheetahLinear::fc decryptToVector");
     I.down(out_vec_share.data(), out, rows);
     I.sync();
   } else {
     Dev w = I.mk(rows * cols), wpts = I.mk(n_out * n_in * N), spts;
-    I.up(w, weight_matrix.data(), rows * cols);
+    if (in_out) {  // [cols][rows] -> [rows][cols], reduced into the ring on the way
+      Dev raw = I.mk(rows * cols);
+      I.up(raw, wd, rows * cols);
+      must(mmh_repack_hwio_to_oihw(raw.p, 1, 1, cols, rows, base_mod_ - 1, w.p, I.stream), "CheetahLinear::fc transpose");
+    } else {
+      I.up(w, wd, rows * cols);
+    }
     must(mmh_fc_encode_weights(plan, w.p, wpts.p, I.stream), "CheetahLinear::fc encodeWeightMatrix error");
     {  // matVecMul rejects a sub-matrix that encodes to zero (hom_fc_ss.cc:414-422); base_mod is a power of two (ctor)
       int64_t split[2];
       must(mmh_fc_plan_info(plan, split, nullptr, nullptr), "plan_info");
       const uint64_t ring_mask = base_mod_ - 1;
       std::vector<uint8_t> nz(n_out * n_in, 0);
-      const uint64_t *wd = weight_matrix.data();
       for (size_t r = 0; r < rows; ++r) {
         uint8_t *row_nz = nz.data() + (r / (size_t)split[0]) * n_in;
         for (size_t cb = 0; cb < n_in; ++cb) {
           if (row_nz[cb]) continue;
           const size_t c1 = std::min<size_t>((cb + 1) * split[1], cols);
           for (size_t c = cb * split[1]; c < c1; ++c)
-            if (wd[r * cols + c] & ring_mask) {
+            if ((in_out ? wd[c * rows + r] : wd[r * cols + c]) & ring_mask) {
               row_nz[cb] = 1;
               break;
             }
@@ -490,7 +554,7 @@ void CheetahLinear::fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64
     }
     Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
     Dev out_cts = I.mk(n_out * 2 * N), share = I.mk(rows);
-    Dev cts = I.recv_cts(n_in, 2 * L * N);
+    Dev cts = I.recv_fresh(I.ring.ctx, n_in);
     must(mmh_fc_server(plan, cts.p, spts.p, wpts.p, I.ring.pk_last.p, (const int64_t *)u.p, (const int64_t *)e1.p, mask.p,
                        out_cts.p, share.p, I.stream),
          "CheetahLinear::fc matmul2D error");
@@ -513,13 +577,12 @@ void CheetahLinear::bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64
   const size_t n_ct = (n + std::min(n, N) - 1) / std::min(n, N);
   if (!out_vector.shape().IsSameSize(meta.vec_shape)) out_vector.Reshape(meta.vec_shape);
   if (party_ == kBob) {
-    Dev vec = I.mk(n), a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct), cts = I.mk(n_ct * 2 * L * N);
+    Impl::Fresh f = I.fresh(I.field.ctx, n_ct);
+    Dev vec = I.mk(n), e = I.noise(n_ct), cts = I.mk(n_ct * 2 * L * N);
     I.up(vec, input_vector.data(), n);
-    must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, vec.p, n, a.p, (const int64_t *)e.p, cts.p, I.stream),
+    must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, vec.p, n, f.a.p, (const int64_t *)e.p, cts.p, I.stream),
          "bn encryptVector");
-    I.stage_cts(cts, n_ct * 2 * L * N);
-    I.sync();
-    I.send_staged(n_ct, 2 * L * N);
+    I.send_fresh(I.field.ctx, cts, f, n_ct);
     Dev res = I.recv_cts(n_ct, 2 * N), out = I.mk(n);
     must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, I.stream), "bn decryptToVector");
     I.down(out_vector.data(), out, n);
@@ -536,7 +599,7 @@ void CheetahLinear::bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64
       must(mmh_bn_encode_vector(I.field.ctx, vec.p, n, in_pts.p, I.stream), "bn encodeVector");
     }
     Dev rnd = I.words(n), out_cts = I.mk(n_ct * 2 * N), share = I.mk(n);
-    Dev cts = I.recv_cts(n_ct, 2 * L * N);
+    Dev cts = I.recv_fresh(I.field.ctx, n_ct);
     must(mmh_bn_server(I.field.ctx, cts.p, in_pts.p, sc_pts.p, n, rnd.p, out_cts.p, share.p, I.stream), "bn failed");
     I.down(out_vector.data(), share, n);
     I.stage_cts(out_cts, n_ct * 2 * N);
@@ -562,13 +625,12 @@ void CheetahLinear::bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor
   if (party_ == kBob) {
     if (!input_tensor.shape().IsSameSize(meta.ishape))
       throw std::runtime_error("bn_direct encryptVector [" + CodeMessage(Code::ERR_CONFIG) + "]");  // hom_bn_ss.cc:527
-    Dev x = I.mk(words), a = I.uniform(I.ring.ctx, 0, n_ct), e = I.noise(n_ct), cts = I.mk(n_ct * 2 * L * N);
+    Impl::Fresh f = I.fresh(I.ring.ctx, n_ct);
+    Dev x = I.mk(words), e = I.noise(n_ct), cts = I.mk(n_ct * 2 * L * N);
     I.up(x, input_tensor.data(), words);
-    must(mmh_bn_encrypt_tensor(I.ring.ctx, &m, I.ring.sk.p, x.p, a.p, (const int64_t *)e.p, cts.p, I.stream),
+    must(mmh_bn_encrypt_tensor(I.ring.ctx, &m, I.ring.sk.p, x.p, f.a.p, (const int64_t *)e.p, cts.p, I.stream),
          "bn_direct encryptVector");
-    I.stage_cts(cts, n_ct * 2 * L * N);
-    I.sync();
-    I.send_staged(n_ct, 2 * L * N);
+    I.send_fresh(I.ring.ctx, cts, f, n_ct);
     Dev res = I.recv_cts(n_ct, 2 * N), out = I.mk(words);
     must(mmh_bn_decrypt_tensor(I.ring.ctx, &m, I.ring.sk_last.p, res.p, out.p, I.stream), "bn_direct decryptToTensor");
     I.down(out_tensor.data(), out, words);
@@ -585,7 +647,7 @@ void CheetahLinear::bn_direct(const Tensor<uint64_t> &input_tensor, const Tensor
       must(mmh_bn_encode_tensor(I.ring.ctx, &m, x.p, in_pts.p, I.stream), "bn_direct encodeVector");
     }
     Dev u = I.ternary(n_ct), e0 = I.noise(n_ct), e1 = I.noise(n_ct), share1 = I.words(words), out_cts = I.mk(n_ct * 2 * N);
-    Dev cts = I.recv_cts(n_ct, 2 * L * N);
+    Dev cts = I.recv_fresh(I.ring.ctx, n_ct);
     must(mmh_bn_direct_server(I.ring.ctx, &m, cts.p, in_pts.p, scales.p, I.ring.pk.p, (const int64_t *)u.p,
                               (const int64_t *)e0.p, (const int64_t *)e1.p, share1.p, out_cts.p, I.stream),
          "bn_direct failed");
@@ -612,15 +674,14 @@ void CheetahLinear::BOLE(const Tensor<uint64_t> &x, const Tensor<uint64_t> &y, c
   I.up(dy, y.data(), n);
   if (party_ == kBob) {
     Dev cts = I.mk(2 * n_ct * ct_words);
+    Impl::Fresh f = I.fresh(I.field.ctx, 2 * n_ct);  // one seed for both vectors' ciphertexts
     for (int k = 0; k < 2; ++k) {  // encryptVector(x), encryptVector(y)  (cheetah-api.cpp:617-621)
-      Dev a = I.uniform(I.field.ctx, 0, n_ct), e = I.noise(n_ct);
-      must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, k ? dy.p : dx.p, n, a.p, (const int64_t *)e.p,
-                                 cts.p + k * n_ct * ct_words, I.stream),
+      Dev e = I.noise(n_ct);
+      must(mmh_bn_encrypt_vector(I.field.ctx, I.field.sk.p, k ? dy.p : dx.p, n, f.a.p + k * n_ct * L * N,
+                                 (const int64_t *)e.p, cts.p + k * n_ct * ct_words, I.stream),
            "BOLE encryptVector");
     }
-    I.stage_cts(cts, 2 * n_ct * ct_words);
-    I.sync();
-    I.send_staged(2 * n_ct, ct_words);
+    I.send_fresh(I.field.ctx, cts, f, 2 * n_ct);
     Dev res = I.recv_cts(n_ct, 2 * N);
     must(mmh_bn_decrypt_vector(I.field.ctx, I.field.sk_last.p, res.p, n, out.p, I.stream), "BOLE decryptToVector");
     // local cross term x_i * y_i (cheetah-api.cpp:648-649)
@@ -632,7 +693,7 @@ void CheetahLinear::BOLE(const Tensor<uint64_t> &x, const Tensor<uint64_t> &y, c
     must(mmh_bn_encode_vector(I.field.ctx, dy.p, n, pts.p, I.stream), "BOLE encodeVector");
     must(mmh_bn_encode_vector(I.field.ctx, dx.p, n, pts.p + n_ct * N, I.stream), "BOLE encodeVector");
     Dev rnd = I.words(n), out_cts = I.mk(n_ct * 2 * N);
-    Dev cts = I.recv_cts(2 * n_ct, ct_words);
+    Dev cts = I.recv_fresh(I.field.ctx, 2 * n_ct);
     must(mmh_bole_server(I.field.ctx, cts.p, pts.p, n, rnd.p, out_cts.p, out.p, I.stream), "BOLE bole");
     must(mmh_bole_cross_term(out.p, dx.p, dy.p, n, field_mod_, I.stream), "BOLE cross term");
     I.down(out_vector.data(), out, n);

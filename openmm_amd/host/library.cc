@@ -37,12 +37,8 @@ void Library::MatMul2D(int32_t d0, int32_t d1, int32_t d2, const intType *mat_A,
   meta.weight_shape = TensorShape({w_cols, w_rows});  // transposed
   meta.is_shared_input = kIsSharedInput;
   const intType *weight_mat = is_A_weight_matrix ? mat_A : mat_B, *input_mat = is_A_weight_matrix ? mat_B : mat_A;
-  Tensor<intType> weight_matrix;
-  if (cheetah_linear->party() == kServer) {
-    weight_matrix.Reshape(meta.weight_shape);
-    for (int64_t r = 0; r < w_rows; ++r)
-      for (int64_t c = 0; c < w_cols; ++c) weight_matrix.data()[c * w_rows + r] = getRingElt(weight_mat[r * w_cols + c]);
-  }
+  // weight_mat is w_rows x w_cols (input x output) row-major; the transposition into meta.weight_shape and
+  // getRingElt happen on the device (fc_in_out)
   for (int64_t r = 0; r < in_rows; ++r) {
     const intType *input_row = input_mat + r * in_cols;
     Tensor<intType> input_vector;
@@ -53,10 +49,9 @@ void Library::MatMul2D(int32_t d0, int32_t d1, int32_t d2, const intType *mat_A,
       std::transform(input_row, input_row + in_cols, input_vector.data(), [this](uint64_t v) { return getRingElt(v); });
     }
     Tensor<uint64_t> out_vec;
-    cheetah_linear->fc(input_vector, weight_matrix, meta, out_vec);
+    cheetah_linear->fc_in_out(input_vector, weight_mat, meta, out_vec);
     std::copy_n(out_vec.data(), out_vec.NumElements(), mat_C + r * in_cols);  // :126-127, as written
   }
-  if (cheetah_linear->party() == kServer) cheetah_linear->safe_erase(weight_matrix.data(), weight_matrix.NumElements());
 }
 
 // :216-300

@@ -103,6 +103,11 @@ SIGNATURES = {
     "mmh_conv_filters_destroy": [_vp],
     "mmh_conv_server_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],
+    "mmh_ct_split_c0": [_vp, C.c_int, _vp, _sz, _vp, _vp],
+    "mmh_ct_join": [_vp, C.c_int, _vp, _vp, _sz, _vp, _vp],
+    "mmh_conv_result_packed_words": [_vp, C.POINTER(_sz)],
+    "mmh_conv_result_pack": [_vp, _vp, _vp, _vp],
+    "mmh_conv_result_unpack": [_vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],
     "mmh_fc_plan_destroy": [_vp],
     "mmh_fc_split": [C.c_int64, C.c_int64, _sz, C.POINTER(C.c_int64)],

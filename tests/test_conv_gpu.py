@@ -43,6 +43,13 @@ def mm():
     return openmm_amd
 
 
+def plan_kept(cv, ref_out):
+    """longest list of kept c0 coefficients over the spatial windows: bounded by the non-zero pattern of the
+    reference ciphertexts (remove_unused_coeffs zeroes everything else; a kept coefficient may be zero by chance)"""
+    nz = (ref_out[:, 0, 0, :] != 0).reshape(-1, cv.n_sp, ref_out.shape[-1]).any(axis=0)
+    return max(int(nz.sum(axis=1).max()), 1) + 64
+
+
 def dev(a):
     import torch
     a = np.ascontiguousarray(a)
@@ -158,6 +165,11 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
     ref_dec = cv.decrypt(np.ascontiguousarray(sk[:1]), ref_out)
     got_dec = host(client.decryptToTensor(got_out, meta))
     assert np.array_equal(got_dec, ref_dec)
+    # the compact wire form of the result: every bit the reference's ciphertext holds comes back, in fewer words
+    packed = server.packResult(got_out, meta)
+    assert np.array_equal(host(client.unpackResult(packed, meta)), ref_out)
+    kept = int(plan_kept(cv, ref_out))
+    assert packed.shape[1] <= (N * 51 + 63) // 64 + (kept * 39 + 63) // 64 and packed.shape[1] < 2 * N
     ideal = ideal_conv(img, filters, same, stride, T)
     diff = (got_dec.astype(object) + host(got_share).astype(object) - ideal) % T
     assert all(d in (0, 1, T - 1) for d in diff.ravel())
