@@ -382,6 +382,26 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
     return out
 
 
+def host_to_host_leg():
+    """The C++ host mirror end to end (tests/cpp/network_linear.cc): every ResNet50 convolution + the FC through
+    Conv2DWrapper / MatMul2D on host arrays, both parties as two threads of one process on this GPU: encryption,
+    ciphertexts through an in-process byte pipe (the stand-in for the network), HE compute, decryption.  Warm pass."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "network_linear")
+    if not os.path.exists(exe):
+        return {}
+    r = subprocess.run([exe, "resnet50", "8"], capture_output=True, text=True, timeout=280)
+    m = re.search(r"ResNet50: 53 convolutions.*?([0-9.]+) ms in total", r.stdout)
+    w = re.search(r"in-process transport.*?: ([0-9.]+) ms for ([0-9.]+) MiB", r.stdout)
+    if r.returncode != 0 or not m or not w:
+        return {"resnet50_host_to_host_error": (r.stdout + r.stderr)[-300:]}
+    return {"resnet50_host_to_host_ms": float(m.group(1)), "resnet50_host_to_host_wire_mib": float(w.group(2)),
+            "resnet50_host_to_host_pipe_copy_ms": float(w.group(1)),
+            "resnet50_host_to_host_note": "C++ host mirror, both parties in one process on one GPU, ciphertexts through "
+                                          "an in-process byte pipe; warm pass (tests/cpp/network_linear.cc)"}
+
+
 def max_over_ranks(x, torch, dist, world):
     if world == 1:
         return x
@@ -511,6 +531,9 @@ def main():
             extra.update(net)
             extra.update(sq)
             extra.update(dn)
+            if world == 1:
+                torch.cuda.synchronize()
+                extra.update(host_to_host_leg())
     if rank == 0:
         line = {
             "metric": "64-bit NTTs/sec (N=4096/8192) + ResNet50 HE-linear ms at 1/2/4/8 GPUs",
@@ -538,7 +561,9 @@ def main():
             ms, threads = cpu_homconv_ms()
             extra["homconv_resnet50_3x3_cpu_port_ms"] = ms
             extra["homconv_resnet50_3x3_cpu_port_note"] = (
-                f"conv2DOneFilter loop only, reference schedule (4096 multiply_plain), oracle port on {threads} host threads")
+                f"conv2DOneFilter loop only, in the REFERENCE'S schedule (4096 multiply_plain, three transforms each), "
+                f"oracle port (not HEXL) on {threads} host threads: the GPU leg runs another schedule, so the ratio of "
+                f"the two is not a like-for-like speed-up")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -263,3 +263,23 @@ def test_bad_arguments(mm):
         g2.mul_plain_acc(dev(np.zeros((2, 2, 2, N), np.uint64)), dev(np.zeros((2, N), np.uint64)),
                          2, 2, 2, 2, 1, 2, 1, 0)
     assert ei.value.code == 6  # ERR_OUT_BOUND
+
+
+def test_fresh_ciphertext_halves_split_and_join(mm):
+    """mmh_ct_split_c0 / mmh_ct_join: the wire form of a fresh symmetric ciphertext is c0 + the seed of c1
+    (seal::Serializable<Ciphertext>, cheetah-api.cpp:11-29): take c0 out, put (c0, c1) back, same bits"""
+    import torch
+    import openmm_amd.lib as L
+    g = mm.Context(N, (60, 49), 1 << 37)
+    lib = L.load_library()
+    cts = torch.randint(0, 1 << 62, (5, 2, 2, N), dtype=torch.int64, device="cuda")
+    c0, back = torch.empty(5, 2, N, dtype=torch.int64, device="cuda"), torch.empty_like(cts)
+    L.check(lib.mmh_ct_split_c0(g.handle, 0, L.dptr(cts), 5, L.dptr(c0), L._stream_ptr()))
+    assert torch.equal(c0, cts[:, 0])
+    c1 = cts[:, 1].contiguous()
+    L.check(lib.mmh_ct_join(g.handle, 0, L.dptr(c0), L.dptr(c1), 5, L.dptr(back), L._stream_ptr()))
+    assert torch.equal(back, cts)
+    last = torch.randint(0, 1 << 59, (3, 2, 1, N), dtype=torch.int64, device="cuda")
+    c0l = torch.empty(3, 1, N, dtype=torch.int64, device="cuda")
+    L.check(lib.mmh_ct_split_c0(g.handle, 1, L.dptr(last), 3, L.dptr(c0l), L._stream_ptr()))
+    assert torch.equal(c0l, last[:, 0])
