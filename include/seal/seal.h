@@ -12,8 +12,9 @@
 // include/mm_gemini, which keeps batches resident and calls one entry point per layer.
 //
 // What is not SEAL: randomness comes from the device ChaCha20 sampler (seeded from the OS or from the caller's
-// UniformRandomGenerator), so streams differ from SEAL's Blake2xb ones; save/load write the raw words behind a
-// small header, not SEAL's zstd-framed format.  Only BFV, n_special_primes = 0, N in {4096, 8192},
+// UniformRandomGenerator), so streams differ from SEAL's Blake2xb ones; save/load write SEAL 3.7's framing with
+// compr_mode none (seal/wire.h: header, members, seeded form, BLAKE2b parms_id; parity unpinned) and refuse a
+// zstd-compressed stream, which an unmodified SEAL writes by default.  Only BFV, n_special_primes = 0, N in {4096, 8192},
 // at most two coefficient moduli -- what cheetah-api.cpp:95-105,:151-162 sets up.
 #pragma once
 #include <algorithm>
@@ -37,6 +38,7 @@
 #include <vector>
 
 #include "mm_hip.h"
+#include "seal/wire.h"
 
 namespace seal {
 
@@ -234,20 +236,11 @@ class EncryptionParameters {
  private:
   friend class SEALContext;
   void rehash() {
-    // the words SEAL hashes (scheme, N, n_special_primes [patch/SEAL.patch:43-71], moduli, t), mixed by splitmix64;
-    // identifies a level inside one process (SEAL's Blake2b value only matters on its wire format)
-    std::vector<std::uint64_t> w{(std::uint64_t)scheme_, poly_modulus_degree_, n_special_primes_};
-    for (const auto &m : coeff_modulus_) w.push_back(m.value());
-    w.push_back(plain_modulus_.value());
-    std::uint64_t h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
-    for (std::size_t i = 0; i < w.size(); ++i)
-      for (int k = 0; k < 4; ++k) {
-        std::uint64_t z = (h[k] ^ w[i]) + 0x9E3779B97F4A7C15ull * (std::uint64_t)(i * 4 + k + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        h[k] = z ^ (z >> 31);
-      }
-    parms_id_ = {h[0] | 1, h[1], h[2], h[3]};
+    // EncryptionParameters::compute_parms_id: BLAKE2b-256 over (scheme, N, n_special_primes [patch/SEAL.patch:43-71],
+    // moduli, t) -- the value that travels in front of every serialised ciphertext (seal/wire.h)
+    std::vector<std::uint64_t> q;
+    for (const auto &m : coeff_modulus_) q.push_back(m.value());
+    parms_id_ = wire::parms_id_hash((std::uint8_t)scheme_, poly_modulus_degree_, n_special_primes_, q, plain_modulus_.value());
   }
   scheme_type scheme_;
   std::size_t n_special_primes_ = 1, poly_modulus_degree_ = 0;
@@ -482,19 +475,22 @@ class Ciphertext {
     if (!cd) throw std::invalid_argument("parms_id is not valid for encryption parameters");
     parms_id_ = parms_id;
     size_ = size;
+    seeded_ = false;
     n_ = cd->parms().poly_modulus_degree();
     l_ = cd->parms().coeff_modulus().size();
     data_.resize(size_ * n_ * l_, 0);
   }
-  void resize(std::size_t size) { size_ = size, data_.resize(size_ * n_ * l_, 0); }
+  void resize(std::size_t size) { size_ = size, seeded_ = false, data_.resize(size_ * n_ * l_, 0); }
   void release() {
-    parms_id_ = parms_id_zero, is_ntt_form_ = false, size_ = n_ = l_ = 0, scale_ = 1.0;
+    parms_id_ = parms_id_zero, is_ntt_form_ = seeded_ = false, size_ = n_ = l_ = 0, scale_ = 1.0;
     data_.clear(), data_.shrink_to_fit();
   }
-  std::uint64_t *data() { return data_.data(); }
+  // (a writable view ends the seeded state: c1 may no longer be what the seed expands to)
+  std::uint64_t *data() { return seeded_ = false, data_.data(); }
   const std::uint64_t *data() const { return data_.data(); }
   std::uint64_t *data(std::size_t k) {
     if (k >= size_) throw std::out_of_range("poly_index must be within [0, size)");
+    seeded_ = false;
     return data_.data() + k * n_ * l_;
   }
   const std::uint64_t *data(std::size_t k) const {
@@ -514,26 +510,46 @@ class Ciphertext {
     return size_ < 2 || std::all_of(data_.begin() + n_ * l_, data_.end(), [](std::uint64_t c) { return c == 0; });
   }
 
-  // Raw words behind a fixed header -- not SEAL's serialisation (no zstd, no seed compression: SURVEY.md 8 f-1);
-  // both ends of a channel must run this library.
+  // SEAL 3.7's serialisation with compr_mode none (seal/wire.h; parity unpinned).  A ciphertext that
+  // came out of encrypt_symmetric as a Serializable carries the seed of its c1 and is written in the seeded form
+  // (c0 + UniformRandomGeneratorInfo): half the bytes, and the loader regenerates c1 with SEAL's Blake2xb expansion.
   std::streamoff save(std::ostream &os) const {
-    const std::uint64_t head[8] = {kMagic, parms_id_[0], parms_id_[1], parms_id_[2], parms_id_[3],
-                                   (std::uint64_t)size_ | ((std::uint64_t)is_ntt_form_ << 32), n_, l_};
-    os.write(reinterpret_cast<const char *>(head), sizeof(head));
-    os.write(reinterpret_cast<const char *>(data_.data()), (std::streamsize)(data_.size() * 8));
-    return (std::streamoff)(sizeof(head) + data_.size() * 8);
+    wire::CtMeta m;
+    m.parms_id = parms_id_, m.is_ntt_form = is_ntt_form_, m.size = size_, m.poly_modulus_degree = n_;
+    m.coeff_modulus_size = l_, m.scale = scale_;
+    const std::string bytes = wire::save_ciphertext(m, data_.data(), seeded_ ? seed_.data() : nullptr);
+    os.write(bytes.data(), (std::streamsize)bytes.size());
+    return (std::streamoff)bytes.size();
   }
   std::streamoff unsafe_load(const SEALContext &context, std::istream &is) {
-    std::uint64_t head[8];
+    std::uint8_t head[wire::kHeaderBytes];
     is.read(reinterpret_cast<char *>(head), sizeof(head));
-    if (!is || head[0] != kMagic) throw std::logic_error("Ciphertext::load: not a ciphertext of this library");
-    const parms_id_type id = {head[1], head[2], head[3], head[4]};
-    resize(context, id, (std::size_t)(head[5] & 0xFFFFFFFFu));
-    if (n_ != head[6] || l_ != head[7]) throw std::logic_error("Ciphertext::load: level mismatch");
-    is_ntt_form_ = (head[5] >> 32) & 1;
-    is.read(reinterpret_cast<char *>(data_.data()), (std::streamsize)(data_.size() * 8));
     if (!is) throw std::logic_error("Ciphertext::load: truncated stream");
-    return (std::streamoff)(sizeof(head) + data_.size() * 8);
+    const std::size_t total = wire::peek_total(head);
+    if (total < sizeof(head) || total > (std::size_t(1) << 32)) throw std::logic_error("Ciphertext::load: bad size field");
+    std::vector<std::uint8_t> bytes(total);
+    std::memcpy(bytes.data(), head, sizeof(head));
+    is.read(reinterpret_cast<char *>(bytes.data() + sizeof(head)), (std::streamsize)(total - sizeof(head)));
+    if (!is) throw std::logic_error("Ciphertext::load: truncated stream");
+    wire::CtMeta m;
+    std::vector<std::uint64_t> words;
+    bool seeded = false;
+    std::uint8_t seed[wire::kSeedBytes];
+    wire::load_ciphertext(bytes.data(), bytes.size(), m, words, seeded, seed);
+    auto cd = context.get_context_data(m.parms_id);
+    if (!cd) throw std::logic_error("ciphertext data is invalid");   // parms_id unknown to this context
+    resize(context, m.parms_id, (std::size_t)m.size);
+    if (n_ != m.poly_modulus_degree || l_ != m.coeff_modulus_size) throw std::logic_error("ciphertext data is invalid");
+    is_ntt_form_ = m.is_ntt_form, scale_ = m.scale;
+    data_ = std::move(words);
+    seeded_ = false;
+    if (seeded) {  // Ciphertext::expand_seed
+      std::vector<std::uint64_t> q;
+      for (const auto &mod : cd->parms().coeff_modulus()) q.push_back(mod.value());
+      wire::Blake2xbPRNG prng(seed);
+      wire::sample_poly_uniform(prng, q, n_, data(1));
+    }
+    return (std::streamoff)total;
   }
   std::streamoff load(const SEALContext &context, std::istream &is) {
     const std::streamoff n = unsafe_load(context, is);
@@ -547,11 +563,14 @@ class Ciphertext {
       }
     return n;
   }
+  // facade: the seed c1 was expanded from (set by Encryptor::encrypt_symmetric's Serializable form)
+  void facade_set_seed(const std::uint8_t (&seed)[wire::kSeedBytes]) { std::memcpy(seed_.data(), seed, wire::kSeedBytes), seeded_ = true; }
+  bool facade_seeded() const { return seeded_; }
 
  private:
-  static constexpr std::uint64_t kMagic = 0x4D264D5F43543031ull;  // "M&M_CT01"
   parms_id_type parms_id_ = parms_id_zero;
-  bool is_ntt_form_ = false;
+  bool is_ntt_form_ = false, seeded_ = false;
+  std::array<std::uint8_t, wire::kSeedBytes> seed_{};
   std::size_t size_ = 0, n_ = 0, l_ = 0;
   double scale_ = 1.0;
   std::vector<std::uint64_t> data_;
@@ -832,13 +851,13 @@ class Encryptor {
   }
   Serializable<Ciphertext> encrypt_symmetric(const Plaintext &plain) const {
     Ciphertext ct;
-    symmetric(&plain, ct);
+    symmetric(&plain, ct, true);
     return Serializable<Ciphertext>(std::move(ct));
   }
   void encrypt_symmetric(const Plaintext &plain, Ciphertext &destination) const { symmetric(&plain, destination); }
   Serializable<Ciphertext> encrypt_zero_symmetric() const {
     Ciphertext ct;
-    symmetric(nullptr, ct);
+    symmetric(nullptr, ct, true);
     return Serializable<Ciphertext>(std::move(ct));
   }
   // with a public key: asymmetric; an encryptor that only holds a secret key answers with a symmetric encryption
@@ -885,7 +904,9 @@ class Encryptor {
   }
 
  private:
-  void symmetric(const Plaintext *plain, Ciphertext &destination) const {
+  // save_seed: the Serializable form.  c1 = a is then expanded on the host from a fresh 64-byte seed exactly as a
+  // SEAL loader will expand it again (wire::Blake2xbPRNG + sample_poly_uniform), so that save() can ship c0 + seed.
+  void symmetric(const Plaintext *plain, Ciphertext &destination, bool save_seed = false) const {
     if (!has_sk_) throw std::logic_error("secret key is not set");
     auto cd = context_.first_context_data();
     const auto &parms = cd->parms();
@@ -896,8 +917,18 @@ class Encryptor {
     std::uint64_t sid;
     facade::DBuf sk(L * N), a(L * N), e(N), pt(N), out(2 * L * N);
     sk.up(sk_.data().data(), L * N);
-    prng->sampler_key(key, &sid);
-    facade::check(mmh_sample_uniform(cd->backend()->ctx, 0, key, sid, a.get(), 1, nullptr), "encrypt_symmetric");
+    std::uint8_t seed[wire::kSeedBytes];
+    if (save_seed) {
+      prng->generate(sizeof(seed), reinterpret_cast<seal_byte *>(seed));
+      std::vector<std::uint64_t> q, host_a(L * N);
+      for (const auto &m : parms.coeff_modulus()) q.push_back(m.value());
+      wire::Blake2xbPRNG expand(seed);
+      wire::sample_poly_uniform(expand, q, N, host_a.data());
+      a.up(host_a.data(), L * N);
+    } else {
+      prng->sampler_key(key, &sid);
+      facade::check(mmh_sample_uniform(cd->backend()->ctx, 0, key, sid, a.get(), 1, nullptr), "encrypt_symmetric");
+    }
     prng->sampler_key(key, &sid);
     facade::check(mmh_sample_noise(key, sid, (std::int64_t *)e.get(), N, nullptr), "encrypt_symmetric");
     if (plain) {
@@ -911,6 +942,7 @@ class Encryptor {
     out.down(destination.data(), 2 * L * N);
     destination.is_ntt_form() = false;
     destination.scale() = 1.0;
+    if (save_seed) destination.facade_set_seed(seed);
   }
   void switch_to_last(Ciphertext &ct) const {
     auto first = context_.first_context_data();
