@@ -314,7 +314,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
 
     srv = HomConv2DSS()
     srv.setUp(ctx, pk_ntt=pk)
-    per_layer, total, cached_total, d2h_total, repl_total = [], 0.0, 0.0, 0.0, 0.0
+    per_layer, total, cached_total, d2h_total, repl_total, online_total, offline_total = [], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0
     for (c, h, w, fh, fw, m, same, stride, count) in (convs or RESNET50_CONVS):
         shared = c != 3  # first conv runs with kIsSharedInput=false (main_resnet50.cpp:4979)
         meta = Meta((c, h, w), (c, fh, fw), m, same, stride, shared)
@@ -336,7 +336,13 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
             prep = srv.prepareFilters(filters, meta)
             cached_total += count * wall_ms(lambda: srv.conv2DSSPrepared(
                 cts, srv.encodeImage(share, meta) if shared else None, prep, meta, rand))
-            del prep
+            # ... and with the input-independent encryptions of zero of the re-sharing made ahead as well (offline
+            # phase; fresh ones are needed per inference, their making is timed apart)
+            zeros = srv.prepareZeros(meta, rand[0])
+            online_total += count * wall_ms(lambda: srv.conv2DSSOnline(cts, share if shared else None, prep, zeros,
+                                                                       meta, rand[1:]))
+            offline_total += count * wall_ms(lambda: srv.prepareZeros(meta, rand[0]))
+            del prep, zeros
         else:
             # output filters sharded over the ranks, one-call form per rank, assembled on rank 0 by (a) one RCCL
             # gather into a pre-sized device buffer, (b) per-rank async D2H into one shared page-locked host buffer
@@ -368,6 +374,9 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
                f"{prefix}_conv_ms_per_shape": per_layer}
         if world == 1:
             out[f"{prefix}_he_linear_prepared_filters_ms"] = cached_total
+            if prepared:
+                out[f"{prefix}_he_linear_online_ms"] = online_total
+                out[f"{prefix}_he_linear_offline_zeros_ms"] = offline_total
         out.update(multi)
         return out
     fc = HomFCSS()
@@ -383,6 +392,14 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
            "resnet50_conv_ms_per_shape": per_layer, "resnet50_sharding": f"output filters x{world}, gather on rank 0" if world > 1 else "none"}
     if world == 1:
         out["resnet50_he_linear_prepared_filters_ms"] = cached_total + fc_ms
+        if prepared:
+            out["resnet50_he_linear_online_ms"] = online_total + fc_ms
+            out["resnet50_he_linear_offline_zeros_ms"] = offline_total
+            out["resnet50_online_note"] = ("online: static weights prepared per model AND the input-independent "
+                                           "pk-encryptions of zero of the re-sharing made ahead of the client's "
+                                           "ciphertexts (mmh_reshare_zero_prepare, fresh per inference: "
+                                           "offline_zeros_ms); the reference does both inside conv2DSS on every call, "
+                                           "which resnet50_he_linear_ms times (FC not split)")
     out.update(multi)
     if "resnet50_he_linear_d2h_ms" in out:
         out["resnet50_he_linear_d2h_ms"] += fc_ms

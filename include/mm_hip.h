@@ -340,6 +340,22 @@ int mmh_conv_server_prepared(const mmh_conv_plan *plan, const uint64_t *d_in_cts
                              const mmh_conv_filters *filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                              const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                              uint64_t *d_out_share, void *stream);
+/* The re-sharing tail split where the layer's input enters it.  addRandomMask's pk-encryption of zero
+ * (asymmetric_encrypt_zero, hom_conv2d_ss.cc:275-340, called at :769) depends on the public key and on fresh
+ * randomness only: mmh_reshare_zero_prepare makes n of them ahead of the inputs -- d_zero [n][2][N], the products
+ * u * pk_j in coefficient form at the last level, without noise (e1 enters in the online pass; e0 is skipped by the
+ * USE_APPROX_RESHARE build, :323-328) -- and mmh_conv_server_online is mmh_conv_server_prepared with that part taken
+ * from d_zero (n = the plan's n_out): one pass instead of two transforms per output ciphertext, same bits as
+ * mmh_conv_server_prepared with the same u.  The reference computes the encryption inside conv2DSS on every call;
+ * a deployment that has idle time before the client's ciphertexts arrive moves it there.  Every d_zero must be used
+ * once (it is the ciphertext's randomness).  Exactly one of d_share_pts (encoded share, as _prepared takes it) and
+ * d_share_raw (the share tensor [C][H][W], as _tensors takes it) for a shared input, neither otherwise. */
+int mmh_reshare_zero_prepare(const mmh_ctx *ctx, const uint64_t *d_pk_ntt_last, const int64_t *d_u, size_t n,
+                             uint64_t *d_zero, void *stream);
+int mmh_conv_server_online(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                           const uint64_t *d_share_raw, const mmh_conv_filters *filters, const uint64_t *d_zero,
+                           const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
+                           void *stream);
 /* Compact wire form of conv2DSS's result ciphertexts [n_out][2][N] (last level).  The reference sends them through
  * seal::Ciphertext::save (cheetah-api.cpp:11-29, :443-444), whose compression squeezes out what
  * truncate_for_decryption (hom_conv2d_ss.cc:418-436) and remove_unused_coeffs (:800-851) zeroed; this pair does it

@@ -20,6 +20,9 @@ int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *
                              int limbs, hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
+int reshare_online_dispatch(const mmh_ctx *ctx, const u64 *d_zero, size_t n, const u64 *d_acc, const int64_t *d_e1,
+                            const u64 *d_mask, u64 *d_out, const uint8_t *d_keep, size_t keep_period,
+                            const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s);
 
 // call-scoped scratch buffer (stream-ordered reuse, see scratch_alloc)
 struct StreamBuf {
@@ -689,6 +692,35 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   return MMH_OK;
 }
 }  // namespace mmh
+
+// The tail split at the point where the inputs enter it.  The pk-encryption of zero under the tail
+// (asymmetric_encrypt_zero, hom_conv2d_ss.cc:275-340: u * pk, two of the tail's three transforms per ciphertext)
+// depends on the key and on fresh randomness only, not on the layer's input: a deployment can make it while it waits
+// for the client (an offline phase), and the online tail is then one pass.  The reference computes it inside
+// conv2DSS on every call, so the headline figures keep it inside; this pair is reported beside them.
+namespace mmh {
+int reshare_tail_online(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_zero,
+                        const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period, u64 *d_out,
+                        hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out) {
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
+  return reshare_online_dispatch(ctx, d_zero, n, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst,
+                                 share_plane, d_share_out, s);
+}
+}  // namespace mmh
+extern "C" int mmh_reshare_zero_prepare(const mmh_ctx *ctx, const uint64_t *d_pk_ntt_last, const int64_t *d_u, size_t n,
+                                        uint64_t *d_zero, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  CHECK_RC(check_bfv(ctx, 1));
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(d_pk_ntt_last && d_u && d_zero, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  StreamBuf u(s);
+  MMH_HIP(u.alloc(n * ctx->N * 8));
+  CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
+  return ntt_inv_product_dispatch(ctx, u.as<u64>(), d_pk_ntt_last, d_zero, n, 1, s);
+}
 
 // Fresh symmetric ciphertexts travel as c0 plus the seed their c1 was expanded from (seal::Serializable<Ciphertext>
 // of encrypt_symmetric, cheetah-api.cpp:11-29 on :401-406): the two halves of [n][2][limbs][N] apart and back together.

@@ -16,6 +16,9 @@ int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
                         u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out);
+int reshare_tail_online(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_zero,
+                        const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period, u64 *d_out,
+                        hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out);
 int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
                         int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
                         hipStream_t s);
@@ -1050,13 +1053,14 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                             const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream,
                             const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr,
                             const mmh_conv_filters *prepared = nullptr, const uint64_t *d_share_raw = nullptr,
-                            uint32_t *d_zero_filter = nullptr) {
+                            uint32_t *d_zero_filter = nullptr, const uint64_t *d_zero_enc = nullptr) {
   const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
   MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!prepared || prepared->plan == p, MMH_ERR_INVALID_ARG);
-  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw || prepared) && d_pk_ntt_last && d_u && d_e1 && d_mask &&
-                  d_out_cts && d_out_share,
+  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw || prepared) && ((d_pk_ntt_last && d_u) || d_zero_enc) &&
+                  d_e1 && d_mask && d_out_cts && d_out_share,
               MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!d_zero_enc || !exact, MMH_ERR_INVALID_ARG);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts || d_share_raw, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
   const mmh_ctx *ctx = p->ctx;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
@@ -1131,8 +1135,11 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && !exact) {
     // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
-    rc = reshare_tail_approx(ctx, (u64 *)acc, !direct, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
-                             d_out_cts, s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share);
+    rc = d_zero_enc
+             ? reshare_tail_online(ctx, (u64 *)acc, !direct, p->n_out, d_zero_enc, d_e1, d_mask, p->d_keep, S, d_out_cts,
+                                   s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share)
+             : reshare_tail_approx(ctx, (u64 *)acc, !direct, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
+                                   d_out_cts, s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share);
   }
   if (exact) {
     // USE_APPROX_RESHARE=0: uniform noise on c0 first, e0 kept, the mask is a plaintext mod t subtracted
@@ -1260,6 +1267,20 @@ extern "C" int mmh_conv_server_prepared(const mmh_conv_plan *p, const uint64_t *
   MMH_REQUIRE(filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                           d_out_share, stream, nullptr, nullptr, filters);
+}
+
+// The online half of a layer whose weights and whose encryptions of zero were prepared ahead of the inputs
+// (mmh_conv_filters_prepare, mmh_reshare_zero_prepare with the layer's n_out): same bits as mmh_conv_server_prepared
+// with the u the zeros were made from.  d_share_raw (the share tensor as it is) or d_share_pts (its encoding), not both.
+extern "C" int mmh_conv_server_online(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share_pts,
+                                      const uint64_t *d_share_raw, const mmh_conv_filters *filters,
+                                      const uint64_t *d_zero, const int64_t *d_e1, const uint64_t *d_mask,
+                                      uint64_t *d_out_cts, uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
+  MMH_REQUIRE(filters && d_zero, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!(d_share_pts && d_share_raw), MMH_ERR_INVALID_ARG);
+  return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, nullptr, nullptr, nullptr, d_e1, d_mask, d_out_cts,
+                          d_out_share, stream, nullptr, nullptr, filters, d_share_raw, nullptr, d_zero);
 }
 
 // ---------------------------------------------------------------- compact wire form of the results

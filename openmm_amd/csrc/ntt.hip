@@ -638,6 +638,24 @@ __global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void ntt_inv_kernel(u64 *_
   }
 }
 
+// The tail alone, for a pk-encryption of zero prepared ahead of the inputs (mmh_reshare_zero_prepare): unit (p, j)
+// reads its component from `zero` [n][2][N] (canonical mod q0, coefficient form) and hands it to the same Emitter the
+// fused kernel ends in, so the two produce the same bits by construction.
+template <int LOGN>
+__global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void reshare_online_kernel(const u64 *__restrict__ zero,
+                                                                                 const DevMod *__restrict__ mods,
+                                                                                 ReshareSink fin) {
+  constexpr int EA = 1 << (LOGN - 8);
+  extern __shared__ __align__(16) u64 lds[];
+  const int t = threadIdx.x;
+  const u64 *__restrict__ z = zero + ((size_t)blockIdx.x << LOGN);
+  u64 x[EA];
+#pragma unroll
+  for (int k = 0; k < EA; ++k) x[k] = z[k * 256 + t];
+  const Emitter<LOGN, SINK_RESHARE> emit(nullptr, fin, mods, blockIdx.x);
+  emit(t, x, lds);
+}
+
 template <int LOGN>
 static constexpr size_t lds_bytes() {
   return ((size_t(1) << LOGN) + (size_t(1) << (LOGN - 4))) * sizeof(u64);
@@ -757,6 +775,29 @@ int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d
   ReshareSink fin{d_acc, d_e1, d_mask, d_out, ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep,
                   keep_period ? keep_period : 1, d_share_dst, share_plane, d_share_out, ctx->bfv};
   return dispatch(ctx, -3, d_out, src, n * 2, 1, 0, s, &fin);
+}
+
+// The same tail from a prepared encryption of zero d_zero [n][2][N] (coefficient form at the last level).
+int reshare_online_dispatch(const mmh_ctx *ctx, const u64 *d_zero, size_t n, const u64 *d_acc, const int64_t *d_e1,
+                            const u64 *d_mask, u64 *d_out, const uint8_t *d_keep, size_t keep_period,
+                            const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s) {
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(n * 2 <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
+  ReshareSink fin{d_acc, d_e1, d_mask, d_out, ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep,
+                  keep_period ? keep_period : 1, d_share_dst, share_plane, d_share_out, ctx->bfv};
+  auto go = [&](auto kern, size_t lds) -> int {
+    if (lds > 48 * 1024)
+      MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n * 2)), dim3(256), lds, s, d_zero, ctx->d_mods, fin);
+    MMH_HIP(hipGetLastError());
+    return (int)MMH_OK;
+  };
+  switch (ctx->logN) {
+    case 12: return go(reshare_online_kernel<12>, lds_bytes<12>());
+    case 13: return go(reshare_online_kernel<13>, lds_bytes<13>());
+    default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
+  }
 }
 
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,

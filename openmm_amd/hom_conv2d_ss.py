@@ -284,6 +284,39 @@ class HomConv2DSS:
                                                       L._stream_ptr()))
         return out_cts, out_share
 
+    # the re-sharing tail split at the point where the input enters it (include/mm_hip.h): the encryptions of zero
+    # under addRandomMask (hom_conv2d_ss.cc:769, :275-340) made ahead of the inputs, the layer call then online only
+    def prepareZeros(self, meta, u):
+        """u [n_out, N] ternary -> [n_out, 2, N]: u * pk_j in coefficient form at the last level"""
+        self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
+        p = self.plan(meta)
+        self._need(tuple(u.shape) == (p.n_out, self.ctx.N) and u.element_size() == 8, 3, "prepareZeros: u shape")
+        zero = self.ctx._empty(p.n_out, 2, self.ctx.N)
+        L.check(self.ctx.lib.mmh_reshare_zero_prepare(self.ctx.handle, L.dptr(self.pk_last), L.dptr(u.contiguous()),
+                                                      p.n_out, L.dptr(zero), L._stream_ptr()))
+        return zero
+
+    def conv2DSSOnline(self, img_share0, share_tensor, prepared, zeros, meta, rand):
+        """conv2DSSPrepared with the encryptions of zero from prepareZeros and the share as the raw tensor
+        (encodeImage fused into the call, as conv2DSSFromTensors does); rand = (e1, mask)"""
+        p = self.plan(meta)
+        self._need(prepared.plan is p, 7, "conv2DSS: filters prepared for another layer")
+        self._need(tuple(img_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 3, "conv2DSS: #ciphertexts")
+        self._need(tuple(zeros.shape) == (p.n_out, 2, self.ctx.N), 3, "conv2DSS: prepared zeros shape")
+        if meta.is_shared_input:
+            self._need(share_tensor is not None and tuple(share_tensor.shape) == tuple(meta.ishape), 3,
+                       "encodeImage: image shape")
+            share_tensor = share_tensor.contiguous()
+        self._check_rand(p, rand, ("e1", "mask"))
+        e1, mask = rand
+        out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
+        out_share = self.ctx._empty(*p.out_shape)
+        L.check(self.ctx.lib.mmh_conv_server_online(p.handle, L.dptr(img_share0), L.dptr(None),
+                                                    L.dptr(share_tensor if meta.is_shared_input else None),
+                                                    prepared.handle, L.dptr(zeros), L.dptr(e1), L.dptr(mask),
+                                                    L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
+        return out_cts, out_share
+
     # decryptToTensor (hom_conv2d_ss.cc:853-941)
     def decryptToTensor(self, enc_tensor, meta):
         self._need(self.sk_ntt is not None, 1, "decrypt without sk")

@@ -76,6 +76,10 @@ def check_routes(monkeypatch, L, ishape, M, same, stride, shared, routes=("0", "
             out, share = srv.conv2DSSPrepared(d_cts, s1, prep, meta, rand)
             assert np.array_equal(host(out), L["ref_out"]), f"route {route}: prepared, output ciphertexts"
             assert np.array_equal(host(share), L["ref_share"]), f"route {route}: prepared, share"
+            zeros = srv.prepareZeros(meta, rand[0])     # the online half alone (include/mm_hip.h)
+            out, share = srv.conv2DSSOnline(d_cts, d_share, prep, zeros, meta, rand[1:])
+            assert np.array_equal(host(out), L["ref_out"]), f"route {route}: online, output ciphertexts"
+            assert np.array_equal(host(share), L["ref_share"]), f"route {route}: online, share"
     if decrypt:
         cli = HomConv2DSS()
         cli.setUp(g, sk_ntt=dev(L["sk"]))

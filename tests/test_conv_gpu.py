@@ -152,6 +152,11 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
         pre_out, pre_share = server.conv2DSSPrepared(got_cts, got_s, prep, meta, (dev(u), dev(e1), dev(mask)))
         assert np.array_equal(host(pre_out), ref_out)
         assert np.array_equal(host(pre_share), ref_share)
+    # ... and the online half alone, the encryptions of zero under the re-sharing made ahead of the input from the same u
+    zeros = server.prepareZeros(meta, dev(u))
+    on_out, on_share = server.conv2DSSOnline(got_cts, dev(share1) if shared else None, prep, zeros, meta,
+                                             (dev(e1), dev(mask)))
+    assert np.array_equal(host(on_out), ref_out) and np.array_equal(host(on_share), ref_share)
     # the USE_APPROX_RESHARE=0 build of the same call: flood noise, e0 kept, mask mod t; exact identity
     flood, e0 = splitmix64(SEED + 60, cv.n_out * N).reshape(cv.n_out, N), noise(SEED + 61, (cv.n_out, N))
     words = splitmix64(SEED + 62, cv.n_out * N).reshape(cv.n_out, N)
