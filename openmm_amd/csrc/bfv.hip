@@ -685,6 +685,20 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   MMH_HIP(u.alloc(n * N * 8));
   if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
   CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
+  // Few output ciphertexts: the fused kernel has one workgroup per component and walks its coefficients in four
+  // batches, each a memory round trip, so below the size where it fills the chip the encryption of zero is written
+  // out and the tail runs one thread per coefficient instead; same bits.  Measured per layer call (GPU time, fused
+  // against split): 64 ciphertexts 66.7 / 59.8 us, 256: 83.5 / 87.3, 512: 111.9 / 128.9, 1024: 203 / 243.
+  // MMH_TAIL_SPLIT_MAX overrides the size (A/B measurements, tests of both forms).
+  const char *split_env = getenv("MMH_TAIL_SPLIT_MAX");
+  const size_t split_max = split_env ? (size_t)atol(split_env) : (size_t)128;
+  if (n <= split_max) {
+    StreamBuf z(s);
+    MMH_HIP(z.alloc(n * 2 * N * 8));
+    CHECK_RC(ntt_inv_product_dispatch(ctx, u.as<u64>(), d_pk_ntt_last, z.as<u64>(), n, 1, s));
+    return reshare_online_dispatch(ctx, z.as<u64>(), n, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst,
+                                   share_plane, d_share_out, s);
+  }
   // u * pk_j back to coefficient form and, coefficient by coefficient, into the tail (ReshareSink, ntt.hip): the
   // encryption of zero is never written
   CHECK_RC(ntt_inv_product_reshare(ctx, u.as<u64>(), d_pk_ntt_last, n, d_acc, d_e1, d_mask, d_out, d_keep,

@@ -31,7 +31,7 @@ struct DevMod {
   u32 fold_shift;              // b - 32
   u32 fold_mask;               // 2^(b-32) - 1
   // q < 2^49: the NTT runs in double precision (exact integer arithmetic through FMA, ntt.hip) and
-  // the second word of every twiddle pair holds the bits of (double)w instead of the Shoup quotient
+  // its table halves hold N doubles (double)w each, compactly, instead of N (w, Shoup quotient) pairs
   u32 f64;
   double qd, qinv;             // (double)q and 1/q rounded to nearest
 };

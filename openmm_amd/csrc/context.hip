@@ -102,18 +102,20 @@ static void build_mod(mmh_ctx *ctx, u64 m, u64 psi, DevMod *out, std::vector<ulo
   // MMH_NTT_F64=0 keeps the integer butterflies for every modulus (A/B measurements, tests)
   const char *env = getenv("MMH_NTT_F64");
   const bool f64 = m < (u64(1) << 49) && !(env && env[0] == '0');
-  auto second = [&](u64 w) {
-    if (!f64) return shoup(w, m);
-    const double d = (double)w;  // exact: w < 2^49
-    u64 bits;
-    memcpy(&bits, &d, sizeof bits);
-    return bits;
-  };
+  // integer moduli: (w, floor(w 2^64 / q)) pairs.  Moduli on the double-precision path need the twiddle as a double
+  // only: a compact table of N doubles at the start of each half (the second N words of the half stay unused), so
+  // that a lane's run of consecutive twiddles is contiguous and the transform pulls half the lines through L2.
   u64 p = 1, ip = 1;
   for (size_t k = 0; k < N; ++k) {
     const uint32_t r = bit_reverse((uint32_t)k, ctx->logN);
-    fwd[r] = make_ulonglong2(p, second(p));
-    inv[r] = make_ulonglong2(ip, second(ip));
+    if (f64) {
+      const double d = (double)p, id = (double)ip;  // exact: below 2^49
+      memcpy(reinterpret_cast<u64 *>(fwd) + r, &d, 8);
+      memcpy(reinterpret_cast<u64 *>(inv) + r, &id, 8);
+    } else {
+      fwd[r] = make_ulonglong2(p, shoup(p, m));
+      inv[r] = make_ulonglong2(ip, shoup(ip, m));
+    }
     p = mul_mod(p, psi, m);
     ip = mul_mod(ip, ipsi, m);
   }

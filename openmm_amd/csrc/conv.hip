@@ -104,27 +104,26 @@ __global__ __launch_bounds__(256) void encode_image_kernel(const u64 *__restrict
 // EncodeImageShare fused with add_plain (conv2DSS :655-671 straight from the share tensor): out = ct + Delta * m
 // with m the coefficient encode_image_kernel would have written; both polynomials of every ciphertext are
 // written, so no copy and no plaintext buffer is needed.  Also clears `n_words` flag words of the call.
-__global__ __launch_bounds__(256) void image_plus_share_kernel(const u64 *__restrict__ in, const u64 *__restrict__ img,
-                                                               u64 *__restrict__ out,
-                                                               const ImgWindow *__restrict__ wins, size_t n_in,
-                                                               int logN, int wc, int wh, int ww, int H, int W,
-                                                               int sub_h, int sub_w, BfvConsts b,
-                                                               const DevMod *__restrict__ mods,
-                                                               u32 *__restrict__ words, int n_words,
-                                                               u32 *__restrict__ one_more) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx < (size_t)n_words) words[idx] = 0;
-  if (idx == 0 && one_more) *one_more = 0;
-  if (idx >= (n_in << logN)) return;
+struct ImageShareArgs {
+  const u64 *in, *img;
+  u64 *out;
+  const ImgWindow *wins;
+  size_t n_in;
+  int logN, wc, wh, ww, H, W, sub_h, sub_w;
+};
+__device__ __forceinline__ void image_plus_share_body(size_t idx, const ImageShareArgs &a, const BfvConsts &b,
+                                                      const DevMod *__restrict__ mods) {
+  if (idx >= (a.n_in << a.logN)) return;
+  const int logN = a.logN;
   const size_t k = idx >> logN;
   const int i = (int)(idx & ((size_t(1) << logN) - 1));
   u64 m = 0;
-  if (img && i < wc * wh * ww) {
-    const ImgWindow g = wins[k];
-    const int c = i / (wh * ww), y = (i / ww) % wh, x = i % ww;
+  if (a.img && i < a.wc * a.wh * a.ww) {
+    const ImgWindow g = a.wins[k];
+    const int c = i / (a.wh * a.ww), y = (i / a.ww) % a.wh, x = i % a.ww;
     if (c < g.nc && y >= g.lo_y && y + g.hi_y < g.nh && x >= g.lo_x && x + g.hi_x < g.nw) {
-      const size_t cc = c + g.c0, yy = (size_t)(y - g.lo_y + g.y0) * sub_h, xx = (size_t)(x - g.lo_x + g.x0) * sub_w;
-      m = red_t(img[(cc * H + yy) * W + xx], b.t);
+      const size_t cc = c + g.c0, yy = (size_t)(y - g.lo_y + g.y0) * a.sub_h, xx = (size_t)(x - g.lo_x + g.x0) * a.sub_w;
+      m = red_t(a.img[(cc * a.H + yy) * a.W + xx], b.t);
     }
   }
   const LevelConsts &c0 = b.lv[0];
@@ -133,11 +132,20 @@ __global__ __launch_bounds__(256) void image_plus_share_kernel(const u64 *__rest
   for (int l = 0; l < 2; ++l) {
     const DevMod &q = mods[l];
     const size_t o0 = (((k * 2) * 2 + l) << logN) + i, o1 = (((k * 2 + 1) * 2 + l) << logN) + i;
-    u64 v = in[o0];
+    u64 v = a.in[o0];
     if (m) v = add_mod(v, scaled_plain(m, fix, c0.delta_mod_q[l], q), q.q);
-    out[o0] = v;
-    out[o1] = in[o1];
+    a.out[o0] = v;
+    a.out[o1] = a.in[o1];
   }
+}
+__global__ __launch_bounds__(256) void image_plus_share_kernel(ImageShareArgs a, BfvConsts b,
+                                                               const DevMod *__restrict__ mods,
+                                                               u32 *__restrict__ words, int n_words,
+                                                               u32 *__restrict__ one_more) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (size_t)n_words) words[idx] = 0;
+  if (idx == 0 && one_more) *one_more = 0;
+  image_plus_share_body(idx, a, b, mods);
 }
 
 // EncodeFilter: scatter filter m, channel c, tap (r, col) to its reversed coefficient
@@ -234,16 +242,24 @@ constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as
 // mod t (the conv2DOneFilter :573-580 rule is evaluated from it by pw_expand_kernel).
 // FROM_PTS: read the weights back from encoded filter plaintexts instead of the raw tensor.
 // w8 layout: [m / 128][k / 64][digit 3][(m % 128) / 16][lane = ((k % 64) / 16) << 4 | m % 16][k % 16].
+struct PwWeightArgs {
+  const u64 *src;
+  u32 *wp;
+  u64 *wl;
+  uint4 *w8;
+  int M, Mpad, Mpad128, C, Cpad, Cpad64;
+  const PwChannel *chan;
+  int n_cslices, logN;
+  ModC t;
+  u64 thr, q0, q1;
+};
+// one thread's filter and group of 16 taps; returns the flag bits in bits 0-1 and "has a weight != 0 mod t" in bit 2
 template <bool FROM_PTS>
-__global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__ src, u32 *__restrict__ wp,
-                                                         u64 *__restrict__ wl, uint4 *__restrict__ w8,
-                                                         u32 *__restrict__ flag, u32 *__restrict__ nzmap, int M,
-                                                         int Mpad, int Mpad128, int C, int Cpad, int Cpad64,
-                                                         const PwChannel *__restrict__ chan, int n_cslices, int logN,
-                                                         ModC t, u64 thr, u64 q0, u64 q1) {
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)(Cpad64 / 16) * Mpad128) return;
-  const int m = (int)(gid % Mpad128), kg = (int)(gid / Mpad128);
+__device__ __forceinline__ u32 pw_weights_body(size_t gid, const PwWeightArgs &a) {
+  if (gid >= (size_t)(a.Cpad64 / 16) * a.Mpad128) return 0;
+  const int M = a.M, Mpad = a.Mpad, C = a.C, Cpad = a.Cpad;
+  const ModC &t = a.t;
+  const int m = (int)(gid % a.Mpad128), kg = (int)(gid / a.Mpad128);
   u32 dig[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   u32 bits = 0;
   bool any = false;
@@ -253,14 +269,14 @@ __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__
     u64 v = 0;  // filters and taps beyond the real ones weigh nothing
     if (m < M && ch < C) {
       if (FROM_PTS) {
-        const PwChannel pc = chan[ch];   // the tap's coefficient in the polynomial of its channel slice
-        v = src[(((size_t)m * n_cslices + pc.row) << logN) + pc.e];
+        const PwChannel pc = a.chan[ch];   // the tap's coefficient in the polynomial of its channel slice
+        v = a.src[(((size_t)m * a.n_cslices + pc.row) << a.logN) + pc.e];
       } else {
-        v = red_t(src[(size_t)m * C + ch], t);
+        v = red_t(a.src[(size_t)m * C + ch], t);
       }
     }
     any |= v != 0;
-    const bool neg = v >= thr;
+    const bool neg = v >= a.thr;
     const u64 mag = neg ? t.q - v : v;
     const bool fits = mag < (u64(1) << kPwBiasLog);
     // balanced byte digits of the signed weight: w = d0 + 256 d1 + 65536 d2, d0 and d1 in [-128, 127]
@@ -275,17 +291,49 @@ __global__ __launch_bounds__(256) void pw_weights_kernel(const u64 *__restrict__
     dig[2][j >> 2] |= (u32)(d2 & 0xff) << sh;
     if (m < Mpad && ch < Cpad) {
       const size_t idx = (size_t)ch * Mpad + m;
-      wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
-      wl[idx] = neg ? v + (q0 - t.q) : v;                            // fast plain lift, limb 0
-      wl[(size_t)Cpad * Mpad + idx] = neg ? v + (q1 - t.q) : v;      // limb 1
+      a.wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
+      a.wl[idx] = neg ? v + (a.q0 - t.q) : v;                            // fast plain lift, limb 0
+      a.wl[(size_t)Cpad * Mpad + idx] = neg ? v + (a.q1 - t.q) : v;      // limb 1
     }
   }
-  if (bits) atomicOr(flag, bits);
-  if (nzmap && any && m < M && nzmap[m] == 0) atomicOr(nzmap + m, 1u);
   const int kc = kg >> 2;
-  const size_t unit = ((((size_t)(m >> 7) * (Cpad64 >> 6) + kc) * 3) * 8 + ((m & 127) >> 4)) * 64 + (((kg & 3) << 4) | (m & 15));
+  const size_t unit = ((((size_t)(m >> 7) * (a.Cpad64 >> 6) + kc) * 3) * 8 + ((m & 127) >> 4)) * 64 + (((kg & 3) << 4) | (m & 15));
 #pragma unroll
-  for (int a = 0; a < 3; ++a) w8[unit + (size_t)a * 8 * 64] = make_uint4(dig[a][0], dig[a][1], dig[a][2], dig[a][3]);
+  for (int d = 0; d < 3; ++d) a.w8[unit + (size_t)d * 8 * 64] = make_uint4(dig[d][0], dig[d][1], dig[d][2], dig[d][3]);
+  return bits | (any && m < M ? 4u : 0u);
+}
+template <bool FROM_PTS>
+__global__ __launch_bounds__(256) void pw_weights_kernel(PwWeightArgs a, u32 *__restrict__ flag,
+                                                         u32 *__restrict__ nzmap) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const u32 r = pw_weights_body<FROM_PTS>(gid, a);
+  if (r & 3u) atomicOr(flag, r & 3u);
+  if (nzmap && (r & 4u)) {
+    const int m = (int)(gid % a.Mpad128);
+    if (nzmap[m] == 0) atomicOr(nzmap + m, 1u);
+  }
+}
+
+// The front of a direct-route layer call from the raw tensors as ONE launch (CheetahLinear::conv2d's server half up
+// to the products, cheetah-api.cpp:417-423): workgroups [0, n_img) build the image (encodeImage fused with
+// add_plain), the others the weight forms.  Nothing here needs a cleared word: every weights workgroup leaves its flag
+// bits in a word of its own (wflag) and every thread its "has a non-zero weight" byte (anymap, [taps / 16][Mpad128]);
+// pw_expand_kernel, the next launch, folds them into the one flag word and the zero-filter verdict.
+__global__ __launch_bounds__(256) void conv_front_kernel(ImageShareArgs ia, BfvConsts b, const DevMod *__restrict__ mods,
+                                                         unsigned n_img, PwWeightArgs wa, u32 *__restrict__ wflag,
+                                                         uint8_t *__restrict__ anymap, u32 *__restrict__ zero_filter) {
+  if (blockIdx.x < n_img) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0 && zero_filter) *zero_filter = 0;
+    image_plus_share_body(idx, ia, b, mods);
+    return;
+  }
+  const unsigned wb = blockIdx.x - n_img;
+  const size_t gid = (size_t)wb * 256 + threadIdx.x;
+  const u32 r = pw_weights_body<false>(gid, wa);
+  if (anymap && gid < (size_t)(wa.Cpad64 / 16) * wa.Mpad128) anymap[gid] = (uint8_t)((r >> 2) & 1u);
+  const int b0 = __syncthreads_or((int)(r & 1u)), b1 = __syncthreads_or((int)(r & 2u));
+  if (threadIdx.x == 0) wflag[wb] = (b0 ? 1u : 0u) | (b1 ? 2u : 0u);
 }
 
 // Two filters against both halves of one column value: four independent v_mad_u64_u32 in one asm
@@ -461,19 +509,44 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr u64 kDigitBias = 0x0080808080808080ull;
 
+struct PwFold {   // what conv_front_kernel left for this launch to fold (all null on the other paths)
+  const u32 *wflag;        // one word of flag bits per weights workgroup
+  int n_wflag;
+  u32 *flag_out;           // the one flag word the product kernels read
+  const uint8_t *anymap;   // [KG][Mpad128] bytes
+  int KG, Mpad128;
+};
 __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ image,
                                                         const PwChannel *__restrict__ chan,
                                                         const int *__restrict__ live, uint4 *__restrict__ u8,
                                                         const u32 *__restrict__ flag, int KC, size_t S, int logN,
                                                         const u32 *__restrict__ nzmap, int M,
-                                                        u32 *__restrict__ zero_filter) {
+                                                        u32 *__restrict__ zero_filter, PwFold fold) {
   // conv2DOneFilter :573-580: some filter all zero mod t?  One workgroup reads the map pw_weights_kernel left.
   if (nzmap && blockIdx.x == 0 && blockIdx.y == 0) {
     int bad = 0;
     for (int m = threadIdx.x; m < M; m += 256) bad |= nzmap[m] == 0;
     if (bad) atomicOr(zero_filter, 1u);
   }
-  if (*flag & 1u) return;
+  if (fold.wflag) {
+    // (the launch after conv_front_kernel: the form is not known yet, so the digits are always written)
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+    if (b == 0) {
+      u32 bits = 0;
+      for (int i = threadIdx.x; i < fold.n_wflag; i += 256) bits |= fold.wflag[i];
+      const int b0 = __syncthreads_or((int)(bits & 1u)), b1 = __syncthreads_or((int)(bits & 2u));
+      if (threadIdx.x == 0) *fold.flag_out = (b0 ? 1u : 0u) | (b1 ? 2u : 0u);
+    }
+    if (fold.anymap) {   // the verdict, filters dealt round robin to the workgroups; every writer stores the same 1
+      for (unsigned m = b; m < (unsigned)M; m += nb) {
+        int any = 0;
+        for (int kg = threadIdx.x; kg < fold.KG; kg += 256) any |= fold.anymap[(size_t)kg * fold.Mpad128 + m];
+        if (!__syncthreads_or(any) && threadIdx.x == 0) *zero_filter = 1u;
+      }
+    }
+  } else if (*flag & 1u) {
+    return;
+  }
   const size_t c0 = (size_t)live[blockIdx.x] * 64;   // first column of the tile: (sp, c0/c1, limb, i)
   const int kc = blockIdx.y, N = 1 << logN;
   const int col = threadIdx.x >> 2, kg = threadIdx.x & 3;
@@ -694,30 +767,32 @@ static PwSizes pw_sizes(const mmh_conv_plan *p) {
   z.Mpad128 = (z.M + 127) / 128 * 128, z.Cpad64 = (z.C + 63) / 64 * 64;
   return z;
 }
+static PwWeightArgs pw_weight_args(const mmh_conv_plan *p, const u64 *src, u32 *wp, u64 *wl, uint8_t *w8) {
+  const mmh_ctx *ctx = p->ctx;
+  const PwSizes z = pw_sizes(p);
+  return PwWeightArgs{src, wp, wl, (uint4 *)w8, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64, p->d_pw_chan,
+                      (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]};
+}
 // weights of the 1x1 route from the raw filters or from encoded plaintexts; flag must be zeroed first
 static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, const u64 *d_filter_pts, u32 *wp,
                              u64 *wl, uint8_t *w8, u32 *flag, hipStream_t s, bool flag_is_clear = false,
                              u32 *nzmap = nullptr) {
-  const mmh_ctx *ctx = p->ctx;
   const PwSizes z = pw_sizes(p);
   if (!flag_is_clear) MMH_HIP(hipMemsetAsync(flag, 0, 4, s));
+  const unsigned blocks = nblk((size_t)(z.Cpad64 / 16) * z.Mpad128);
   if (d_filters_raw)
-    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(nblk((size_t)(z.Cpad64 / 16) * z.Mpad128)), dim3(256), 0, s,
-                       d_filters_raw, wp, wl, (uint4 *)w8, flag, nzmap, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64,
-                       p->d_pw_chan,
-                       (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+    hipLaunchKernelGGL(pw_weights_kernel<false>, dim3(blocks), dim3(256), 0, s, pw_weight_args(p, d_filters_raw, wp, wl, w8),
+                       flag, nzmap);
   else
-    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(nblk((size_t)(z.Cpad64 / 16) * z.Mpad128)), dim3(256), 0, s,
-                       d_filter_pts, wp, wl, (uint4 *)w8, flag, nzmap, z.M, z.Mpad, z.Mpad128, z.C, z.Cpad, z.Cpad64,
-                       p->d_pw_chan,
-                       (int)p->n_cslices, ctx->logN, ctx->bfv.t, ctx->bfv.thr, ctx->q[0], ctx->q[1]);
+    hipLaunchKernelGGL(pw_weights_kernel<true>, dim3(blocks), dim3(256), 0, s, pw_weight_args(p, d_filter_pts, wp, wl, w8),
+                       flag, nzmap);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
                              const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1,
-                             const u32 *nzmap = nullptr, u32 *zero_filter = nullptr) {
+                             const u32 *nzmap = nullptr, u32 *zero_filter = nullptr, const PwFold *fold = nullptr) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const PwSizes z = pw_sizes(p);
@@ -740,7 +815,8 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     }
     if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
     hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_chan,
-                       p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter);
+                       p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter,
+                       fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0});
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
                        ctx->logN, ctx->d_mods);
@@ -1067,12 +1143,13 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
   void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr, *mask_t = nullptr;
+  void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *anymap = nullptr;   // weight forms of a fresh direct-route call
   void *flag_word = nullptr;   // the direct route's weight-form flag, cleared by the kernel that builds the image
   // the route: prepared filters carry the one they were prepared for
   const bool direct = prepared ? prepared->w8 != nullptr : p->direct_fresh;
   int rc = MMH_OK;
   auto cleanup = [&]() {
-    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word})
+    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word, wp, wl, w8, anymap})
       if (b) (void)scratch_free(b, s);
   };
   auto grab = [&](void **b, size_t bytes) {
@@ -1085,16 +1162,35 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // The conv2DOneFilter :573-580 verdict, when the caller wants it from this call: on the direct route it falls
   // out of the weight pass (a map of filters with a non-zero weight, read by the next kernel), else a pass of its own
   const bool via_image_kernel = d_share_raw && p->meta.is_shared_input;
-  const bool nz_inline = d_zero_filter && via_image_kernel && direct && !prepared && d_filters_raw && pw_mfma_enabled(ctx);
-  if (!rc && via_image_kernel) {
-    const int n_words = direct && !prepared ? 1 + (nz_inline ? (int)M : 0) : 0;
+  const ImageShareArgs img_args{d_in_cts, d_share_raw, (u64 *)image, p->d_windows, p->n_in, ctx->logN,
+                                (int)p->split.win_c, (int)p->split.win_h, (int)p->split.win_w, (int)p->in.h, (int)p->in.w,
+                                p->sub_h, p->sub_w};
+  // the front of a fresh direct-route call from the raw tensors is one launch (conv_front_kernel): image and weight
+  // forms side by side, flag bits and the zero-filter map left for the digit kernel to fold
+  const bool front = via_image_kernel && direct && !prepared && d_filters_raw && pw_mfma_enabled(ctx);
+  const bool nz_inline = d_zero_filter && front;
+  PwFold fold{nullptr, 0, nullptr, nullptr, 0, 0};
+  if (!rc && front) {
+    const PwSizes z = pw_sizes(p);
+    const unsigned n_img = nblk(p->n_in << ctx->logN), n_w = nblk((size_t)(z.Cpad64 / 16) * z.Mpad128);
+    grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
+    grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
+    grab(&w8, z.w8_bytes());
+    grab(&flag_word, 4 * (size_t)(1 + n_w));              // the folded word, then one word per weights workgroup
+    if (nz_inline) grab(&anymap, (size_t)(z.Cpad64 / 16) * z.Mpad128);
+    if (!rc) {
+      fold = PwFold{(const u32 *)flag_word + 1, (int)n_w, (u32 *)flag_word, (const uint8_t *)anymap, z.Cpad64 / 16, z.Mpad128};
+      hipLaunchKernelGGL(conv_front_kernel, dim3(n_img + n_w), dim3(256), 0, s, img_args, ctx->bfv, ctx->d_mods, n_img,
+                         pw_weight_args(p, d_filters_raw, (u32 *)wp, (u64 *)wl, (uint8_t *)w8), (u32 *)flag_word + 1,
+                         (uint8_t *)anymap, d_zero_filter);
+      if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+    }
+  } else if (!rc && via_image_kernel) {
+    const int n_words = direct && !prepared ? 1 : 0;
     if (n_words) grab(&flag_word, 4 * (size_t)n_words);
     if (!rc) {
-      const size_t total = p->n_in << ctx->logN;
-      hipLaunchKernelGGL(image_plus_share_kernel, dim3(nblk(total)), dim3(256), 0, s, d_in_cts, d_share_raw,
-                         (u64 *)image, p->d_windows, p->n_in, ctx->logN, (int)p->split.win_c, (int)p->split.win_h,
-                         (int)p->split.win_w, (int)p->in.h, (int)p->in.w, p->sub_h, p->sub_w, ctx->bfv, ctx->d_mods,
-                         (u32 *)flag_word, n_words, d_zero_filter);
+      hipLaunchKernelGGL(image_plus_share_kernel, dim3(nblk(p->n_in << ctx->logN)), dim3(256), 0, s, img_args, ctx->bfv,
+                         ctx->d_mods, (u32 *)flag_word, n_words, d_zero_filter);
       if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
     }
   } else {
@@ -1120,9 +1216,11 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && direct && prepared)
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
                            (u64 *)acc, s, exact, prepared->form);
-  if (!rc && direct && !prepared)
-    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word,
-                       nz_inline ? (u32 *)flag_word + 1 : nullptr, nz_inline ? d_zero_filter : nullptr);
+  if (!rc && front)
+    rc = pointwise_product(p, (const u64 *)image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8,
+                           (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold);
+  if (!rc && direct && !prepared && !front)
+    rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
   if (!rc && !direct && !prepared && d_filters_raw)
     rc = ntt_filter_dispatch(ctx, d_filters_raw, (u64 *)f_ntt, M, (int)p->f.c, (int)p->f.h, (int)p->f.w,
                              (int)p->split.win_c, (int)Cs, p->filt_origin, p->split.win_h * p->split.win_w,

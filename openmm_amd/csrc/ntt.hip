@@ -14,6 +14,7 @@
 // every access pattern of the three passes bank-conflict free for ds_read_b64/ds_write_b64.
 #include "common.hpp"
 #include "bfv_device.hpp"
+#include "host_math.hpp"
 
 namespace mmh {
 
@@ -131,6 +132,7 @@ __device__ __forceinline__ void inv_radix(u64 (&x)[1 << R], const ulonglong2 (&t
 //   inverse  inputs centred to |v| <= 1; sums are reduced every other stage, the fixed point of the
 //            recurrence is B = 2 at even stages, differences stay <= 8.
 // The final value is reduced to [0, q), so the visible result is that of the integer kernels.
+// Twiddles of such a modulus are a compact table of doubles at the start of its table half (context.hip).
 #pragma clang fp contract(off)
 struct F64Mod { double q, qinv; };
 __device__ __forceinline__ double f64_mulmod(double w, double y, const F64Mod &m) {
@@ -159,7 +161,7 @@ __device__ __forceinline__ void load_twiddles_f64(const ulonglong2 *__restrict__
   for (int u = 0; u < R; ++u)
 #pragma unroll
     for (int b = 0; b < (1 << u); ++b)
-      w[(1 << u) - 1 + b] = __longlong_as_double((long long)tw[(1u << (S0 + u)) + (jhi << u) + b].y);
+      w[(1 << u) - 1 + b] = reinterpret_cast<const double *>(tw)[(1u << (S0 + u)) + (jhi << u) + b];
 }
 // same index pattern as fwd_radix / inv_radix
 template <int R, bool REDUCE_FIRST>
@@ -415,6 +417,54 @@ struct ReshareSink {
   size_t share_plane;
   u64 *share_out;
   BfvConsts b;
+  // constants as (w, floor(w 2^64 / q)) pairs for the fixed multipliers of the tail: q1^-1 mod q0, and for the share
+  // of a power-of-two ring t*gamma mod q0 and -q0^-1 mod gamma (fast = 1; else the general behz_round)
+  u64 inv_qlast_sh, sh_c, sh_c_sh, sh_ng, sh_ng_sh;
+  int fast, qlast_small;
+};
+// The tail's arithmetic on one coefficient (shared by the fused kernel's Emitter and the element-wise kernel):
+// divide_and_round_q_last of the accumulator, + the encryption of zero, then e1 (c1) or - mask (c0), truncation.
+struct ReshareCoeff {
+  const ReshareSink &f;
+  const DevMod *__restrict__ mods;
+  const DevMod &q0;
+  u64 q1, half, half0;
+  __device__ __forceinline__ ReshareCoeff(const ReshareSink &f_, const DevMod *mods_)
+      : f(f_), mods(mods_), q0(mods_[0]), q1(mods_[1].q), half(mods_[1].q >> 1), half0(reduce64(mods_[1].q >> 1, mods_[0])) {}
+  // x * w mod q in [0, q) for a fixed w with its quotient wsh: the same canonical value as Barrett's mul_mod
+  __device__ __forceinline__ static u64 mul_fixed(u64 x, u64 w, u64 wsh, u64 q) {
+    const u64 v = shoup_mad_uniform(0, x, w, wsh, 0 - q);   // [0, 3q)
+    return csub(csub(v, 2 * q), q);
+  }
+  __device__ __forceinline__ u64 switched(u64 a0, u64 a1, u64 zz) const {
+    const u64 last = csub(a1 + half, q1);
+    const u64 lastq = f.qlast_small ? last : reduce64(last, q0);   // q1 < q0: already reduced
+    const u64 tmp = sub_mod(lastq, half0, q0.q);
+    return add_mod(mul_fixed(sub_mod(a0, tmp, q0.q), f.inv_qlast, f.inv_qlast_sh, q0.q), zz, q0.q);
+  }
+  __device__ __forceinline__ u64 c1(u64 a0, u64 a1, u64 zz, int64_t e) const {
+    return add_mod(switched(a0, a1, zz), signed_to_mod(e, q0.q), q0.q) & f.mask1;
+  }
+  __device__ __forceinline__ u64 c0(u64 a0, u64 a1, u64 zz, u64 m, bool kept) const {
+    const u64 r = sub_mod(switched(a0, a1, zz), m, q0.q) & f.mask0;
+    return kept ? r : 0;
+  }
+  // the other party's share: scale-and-round of the mask at a target coefficient (RNSTool::decrypt_scale_and_round
+  // on one limb).  With t a power of two and gamma above q0 the general routine's nine Barrett reductions come down
+  // to two fixed multiplications and masks: at the last level Q = q0, so v = m t gamma mod q0 enters both bases as it
+  // is, the gamma side is v (-q0^-1) mod gamma, and everything modulo t is a mask (2^64 is a multiple of t).
+  __device__ __forceinline__ u64 share(u64 m) const {
+    if (!f.fast) {
+      const u64 x[2] = {m, 0};
+      return behz_round(x, f.b, f.b.lv[1], mods);
+    }
+    const u64 tm = f.b.t.q - 1, g = f.b.gamma.q;
+    const u64 v = mul_fixed(m, f.sh_c, f.sh_c_sh, q0.q);
+    const u64 vt = (v * f.b.lv[1].neg_inv_q_mod_t) & tm;
+    const u64 vg = mul_fixed(v, f.sh_ng, f.sh_ng_sh, g);
+    const u64 r = (vg > (g >> 1) ? vt + (g - vg) : vt - vg) & tm;
+    return (r * f.b.inv_gamma_mod_t) & tm;
+  }
 };
 template <int LOGN, int SINK>
 struct Emitter {
@@ -440,15 +490,9 @@ struct Emitter {
     for (int k = 0; k < EA; ++k) lds[pad(k * 256 + t)] = zr[k];
     const u64 *z = lds + pad(t);  // coefficient k*256 + t at z[17 * 16 * k]
     constexpr int ZS = 256 + 16;
-    const DevMod &q0 = mods[0];
-    const u64 q1 = mods[1].q, half = q1 >> 1, half0 = reduce64(half, q0);
+    const ReshareCoeff rc(f, mods);
     const u64 *__restrict__ acc0 = f.acc + (((p * 2 + j) * 2) << LOGN), *__restrict__ acc1 = acc0 + (size_t(1) << LOGN);
     u64 *__restrict__ dst = f.out + ((p * 2 + j) << LOGN);
-    auto switched = [&](u64 a0, u64 a1, u64 zz) {  // divide_and_round_q_last, then the encryption of zero
-      const u64 last = csub(a1 + half, q1);
-      const u64 tmp = sub_mod(reduce64(last, q0), half0, q0.q);
-      return add_mod(mul_mod(sub_mod(a0, tmp, q0.q), f.inv_qlast, q0), zz, q0.q);
-    };
     if (j == 1) {
       const int64_t *__restrict__ e1 = f.e1 ? f.e1 + (p << LOGN) : nullptr;
 #pragma unroll 1
@@ -461,10 +505,7 @@ struct Emitter {
           a0[k] = acc0[i], a1[k] = acc1[i], e[k] = e1 ? e1[i] : 0;
         }
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-          const u64 r = add_mod(switched(a0[k], a1[k], z[(h + k) * ZS]), signed_to_mod(e[k], q0.q), q0.q);
-          dst[(h + k) * 256 + t] = r & f.mask1;
-        }
+        for (int k = 0; k < H; ++k) dst[(h + k) * 256 + t] = rc.c1(a0[k], a1[k], z[(h + k) * ZS], e[k]);
       }
       return;
     }
@@ -490,12 +531,8 @@ struct Emitter {
       }
 #pragma unroll
       for (int k = 0; k < H; ++k) {
-        if (d[k] >= 0) {  // the other party's share: scale-and-round of the mask at the target coefficients
-          const u64 x[2] = {m[k], 0};
-          share[d[k]] = behz_round(x, f.b, f.b.lv[1], mods);
-        }
-        const u64 r = sub_mod(switched(a0[k], a1[k], z[(h + k) * ZS]), m[k], q0.q) & f.mask0;
-        dst[(h + k) * 256 + t] = kept[k] ? r : 0;
+        if (d[k] >= 0) share[d[k]] = rc.share(m[k]);
+        dst[(h + k) * 256 + t] = rc.c0(a0[k], a1[k], z[(h + k) * ZS], m[k], kept[k]);
       }
     }
   }
@@ -638,22 +675,32 @@ __global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void ntt_inv_kernel(u64 *_
   }
 }
 
-// The tail alone, for a pk-encryption of zero prepared ahead of the inputs (mmh_reshare_zero_prepare): unit (p, j)
-// reads its component from `zero` [n][2][N] (canonical mod q0, coefficient form) and hands it to the same Emitter the
-// fused kernel ends in, so the two produce the same bits by construction.
-template <int LOGN>
-__global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void reshare_online_kernel(const u64 *__restrict__ zero,
-                                                                                 const DevMod *__restrict__ mods,
-                                                                                 ReshareSink fin) {
-  constexpr int EA = 1 << (LOGN - 8);
-  extern __shared__ __align__(16) u64 lds[];
-  const int t = threadIdx.x;
-  const u64 *__restrict__ z = zero + ((size_t)blockIdx.x << LOGN);
-  u64 x[EA];
-#pragma unroll
-  for (int k = 0; k < EA; ++k) x[k] = z[k * 256 + t];
-  const Emitter<LOGN, SINK_RESHARE> emit(nullptr, fin, mods, blockIdx.x);
-  emit(t, x, lds);
+// The tail alone, one thread per coefficient, for an encryption of zero that exists in memory: prepared ahead of the
+// inputs (mmh_reshare_zero_prepare), or written by a separate inverse transform when the call has so few output
+// ciphertexts that the fused kernel's one workgroup per component would leave most of the chip idle and pay its
+// batches' memory round trips one after the other.  `zero` [n][2][N] canonical mod q0; same ReshareCoeff arithmetic as
+// the fused kernel's Emitter, so the same bits.
+__global__ __launch_bounds__(256) void reshare_elem_kernel(const u64 *__restrict__ zero, const DevMod *__restrict__ mods,
+                                                           ReshareSink f, int logN, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t unit = idx >> logN, p = unit >> 1;
+  const int i = (int)(idx & ((size_t(1) << logN) - 1)), j = (int)(unit & 1);
+  const ReshareCoeff rc(f, mods);
+  const size_t a = (((p * 2 + j) * 2) << logN) + i;
+  const u64 zz = zero[idx];
+  if (j == 1) {
+    const int64_t e = f.e1 ? f.e1[(p << logN) + i] : 0;
+    f.out[idx] = rc.c1(f.acc[a], f.acc[a + (size_t(1) << logN)], zz, e);
+    return;
+  }
+  const size_t kp = ((p % f.keep_period) << logN) + i;
+  const bool kept = !f.keep || f.keep[kp] != 0;
+  const int d = f.share_dst ? f.share_dst[kp] : -1;
+  const u64 m = f.mask[(p << logN) + i];
+  if (d >= 0) f.share_out[(p / f.keep_period) * f.share_plane + d] = rc.share(m);
+  const u64 a0 = kept ? f.acc[a] : 0, a1 = kept ? f.acc[a + (size_t(1) << logN)] : 0;
+  f.out[idx] = rc.c0(a0, a1, zz, m, kept);
 }
 
 template <int LOGN>
@@ -764,6 +811,22 @@ int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *
   return dispatch(ctx, -2, d_out, src, n * 2, limbs, 0, s);
 }
 
+static ReshareSink make_sink(const mmh_ctx *ctx, const u64 *d_acc, const int64_t *d_e1, const u64 *d_mask, u64 *d_out,
+                             const uint8_t *d_keep, size_t keep_period, const int *d_share_dst, size_t share_plane,
+                             u64 *d_share_out) {
+  const BfvConsts &b = ctx->bfv;
+  const u64 q0 = ctx->q[0], g = b.gamma.q;
+  ReshareSink f{d_acc, d_e1, d_mask, d_out, b.inv_qlast_mod_q0, b.mask0, b.mask1, d_keep, keep_period ? keep_period : 1,
+                d_share_dst, share_plane, d_share_out, b, 0, 0, 0, 0, 0, 0, 0};
+  f.inv_qlast_sh = shoup(b.inv_qlast_mod_q0, q0);
+  f.qlast_small = ctx->L == 2 && ctx->q[1] < q0;
+  // last level: one limb, Q = q0, so inv_punct = punct = 1
+  f.fast = b.t_log2 >= 0 && g > q0 && (g >> 62) == 0 && b.lv[1].inv_punct_mod_q[0] == 1 && b.lv[1].punct_mod_gamma[0] == 1 &&
+           (b.t.q == 1 || b.lv[1].punct_mod_t[0] == 1);
+  f.sh_c = b.lv[1].prod_t_gamma_mod_q[0], f.sh_c_sh = shoup(f.sh_c, q0);
+  f.sh_ng = b.lv[1].neg_inv_q_mod_gamma, f.sh_ng_sh = g ? shoup(f.sh_ng, g) : 0;
+  return f;
+}
 // The re-sharing tail of n output ciphertexts from u in NTT form: components (p, j) = INTT(u_ntt[p] (.) key[j])
 // at the last level go through ReshareSink into out / share_out; nothing else is written.
 int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, size_t n, const u64 *d_acc,
@@ -772,32 +835,22 @@ int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d
                             hipStream_t s) {
   NttSource src{};
   src.p = d_u_ntt, src.p2 = d_key;
-  ReshareSink fin{d_acc, d_e1, d_mask, d_out, ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep,
-                  keep_period ? keep_period : 1, d_share_dst, share_plane, d_share_out, ctx->bfv};
+  const ReshareSink fin = make_sink(ctx, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst, share_plane, d_share_out);
   return dispatch(ctx, -3, d_out, src, n * 2, 1, 0, s, &fin);
 }
 
-// The same tail from a prepared encryption of zero d_zero [n][2][N] (coefficient form at the last level).
+// The same tail from an encryption of zero in memory, d_zero [n][2][N] (coefficient form at the last level).
 int reshare_online_dispatch(const mmh_ctx *ctx, const u64 *d_zero, size_t n, const u64 *d_acc, const int64_t *d_e1,
                             const u64 *d_mask, u64 *d_out, const uint8_t *d_keep, size_t keep_period,
                             const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s) {
   if (n == 0) return MMH_OK;
-  MMH_REQUIRE(n * 2 <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
-  ReshareSink fin{d_acc, d_e1, d_mask, d_out, ctx->bfv.inv_qlast_mod_q0, ctx->bfv.mask0, ctx->bfv.mask1, d_keep,
-                  keep_period ? keep_period : 1, d_share_dst, share_plane, d_share_out, ctx->bfv};
-  auto go = [&](auto kern, size_t lds) -> int {
-    if (lds > 48 * 1024)
-      MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n * 2)), dim3(256), lds, s, d_zero, ctx->d_mods, fin);
-    MMH_HIP(hipGetLastError());
-    return (int)MMH_OK;
-  };
-  switch (ctx->logN) {
-    case 12: return go(reshare_online_kernel<12>, lds_bytes<12>());
-    case 13: return go(reshare_online_kernel<13>, lds_bytes<13>());
-    default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
-  }
+  const size_t total = (n * 2) << ctx->logN;
+  MMH_REQUIRE((total + 255) / 256 <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
+  const ReshareSink fin = make_sink(ctx, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst, share_plane, d_share_out);
+  hipLaunchKernelGGL(reshare_elem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_zero, ctx->d_mods, fin,
+                     ctx->logN, total);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
 }
 
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs,

@@ -67,9 +67,15 @@ def check_routes(monkeypatch, L, ishape, M, same, stride, shared, routes=("0", "
             monkeypatch.setenv("MMH_CONV_POINTWISE", route)     # read when the plan is made
         srv = HomConv2DSS()
         srv.setUp(g, pk_ntt=dev(L["pk"]))
-        out, share = srv.conv2DSSFromTensors(d_cts, d_share, d_filters, meta, rand)
-        assert np.array_equal(host(out), L["ref_out"]), f"route {route}: output ciphertexts"
-        assert np.array_equal(host(share), L["ref_share"]), f"route {route}: share"
+        # the re-sharing tail has two forms picked by the number of output ciphertexts (bfv.hip): both, and the default
+        for split_max in ("0", "1000000", None):
+            if split_max is None:
+                monkeypatch.delenv("MMH_TAIL_SPLIT_MAX", raising=False)
+            else:
+                monkeypatch.setenv("MMH_TAIL_SPLIT_MAX", split_max)     # read on every call
+            out, share = srv.conv2DSSFromTensors(d_cts, d_share, d_filters, meta, rand)
+            assert np.array_equal(host(out), L["ref_out"]), f"route {route}, tail {split_max}: output ciphertexts"
+            assert np.array_equal(host(share), L["ref_share"]), f"route {route}, tail {split_max}: share"
         if prepared:
             prep = srv.prepareFilters(d_filters, meta)
             s1 = srv.encodeImage(d_share, meta) if shared else None

@@ -1,4 +1,6 @@
 """GPU parity of the HomFCSS and HomBNSS (BOLE) layer calls vs the oracle flows, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -64,6 +66,13 @@ def test_fc_layer_bit_exact(mm, rows, cols, shared):
     mask = rns_uniform(o, SEED + 8, fc.n_out, 1)[:, 0]
     ref_out, ref_share = fc.server(ref_cts, ref_s, ref_w, np.ascontiguousarray(pk[:, :1]), u, e1, mask)
     got_out, got_share = server.matVecMul(got_w, got_cts, got_s, meta, (dev(u), dev(e1), dev(mask)))
+    # (the fused form of the re-sharing tail too: the default picks the split form for so few ciphertexts, bfv.hip)
+    os.environ["MMH_TAIL_SPLIT_MAX"] = "0"
+    try:
+        f_out, f_share = server.matVecMul(got_w, got_cts, got_s, meta, (dev(u), dev(e1), dev(mask)))
+    finally:
+        del os.environ["MMH_TAIL_SPLIT_MAX"]
+    assert np.array_equal(host(f_out), host(got_out)) and np.array_equal(host(f_share), host(got_share))
     assert np.array_equal(host(got_out), ref_out)
     assert np.array_equal(host(got_share), ref_share)
     # USE_APPROX_RESHARE=0 build: bit-exact against the oracle, and the shares reconstruct exactly
