@@ -71,6 +71,13 @@ int mmh_get_device(int *device);
 int mmh_set_device(int device);
 int mmh_stream_create(void **stream);
 int mmh_stream_destroy(void *stream);
+/* Events (hipEvent_t as void*, timing disabled): a point in a stream that the host can wait for without waiting for
+ * what was enqueued behind it -- how a caller reads an early verdict (mmh_conv_server_tensors_ev) while the rest of
+ * its call still runs.  No counterpart in the reference. */
+int mmh_event_create(void **event);
+int mmh_event_destroy(void *event);
+int mmh_event_record(void *event, void *stream);
+int mmh_event_sync(void *event);
 /* Page-lock memory the caller already owns (a buffer mapped by several processes, a transport's send buffer) so that
  * copies to and from it run asynchronously at the link's rate; fails with ERR_SEAL_MEMORY when the driver refuses the
  * range (the copy then still works, through the driver's bounce buffers).  No counterpart in the reference. */
@@ -322,6 +329,16 @@ int mmh_conv_server_tensors(const mmh_conv_plan *plan, const uint64_t *d_in_cts,
                             const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                             const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                             uint64_t *d_out_share, uint32_t *d_zero_filter, void *stream);
+/* mmh_conv_server_tensors whose zero-filter verdict can be read EARLY: `zero_filter` may point into page-locked host
+ * memory (mmh_host_alloc, torch pinned memory: the kernels store to it directly, no atomics), and `verdict_event`
+ * (mmh_event_create; may be NULL) is recorded on the stream right behind the launch that settles the word -- the second
+ * launch of the call on the direct route -- so the caller waits for that event alone, reads the word and raises the
+ * reference's error (conv2DOneFilter :573-580 returns before it computes) while the products and the re-sharing of
+ * this call, and whatever it enqueued after it, are still running.  No extra launch, clear or copy for the verdict. */
+int mmh_conv_server_tensors_ev(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share,
+                               const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                               const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                               uint64_t *d_out_share, uint32_t *zero_filter, void *verdict_event, void *stream);
 /* The conv2DOneFilter :573-580 rule on the raw filters [M][C][fh][fw]: *d_flag (device word) becomes 1
  * when some filter is all zero mod t, else 0.  Asynchronous, so a caller can read the verdict back after
  * it has enqueued the layer. */

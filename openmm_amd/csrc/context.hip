@@ -372,6 +372,28 @@ extern "C" int mmh_stream_destroy(void *stream) {
   if (stream) MMH_HIP(hipStreamDestroy((hipStream_t)stream));
   return MMH_OK;
 }
+// events for callers without a HIP toolchain: a point in a stream the host can wait for without draining the stream
+extern "C" int mmh_event_create(void **event) {
+  MMH_REQUIRE(event, MMH_ERR_NULL_POINTER);
+  hipEvent_t e = nullptr;
+  MMH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = (void *)e;
+  return MMH_OK;
+}
+extern "C" int mmh_event_destroy(void *event) {
+  if (event) MMH_HIP(hipEventDestroy((hipEvent_t)event));
+  return MMH_OK;
+}
+extern "C" int mmh_event_record(void *event, void *stream) {
+  MMH_REQUIRE(event, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return MMH_OK;
+}
+extern "C" int mmh_event_sync(void *event) {
+  MMH_REQUIRE(event, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipEventSynchronize((hipEvent_t)event));
+  return MMH_OK;
+}
 extern "C" int mmh_host_register(void *h_ptr, size_t bytes) {
   MMH_REQUIRE(h_ptr && bytes, MMH_ERR_NULL_POINTER);
   const hipError_t e = hipHostRegister(h_ptr, bytes, hipHostRegisterDefault);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void zero_filter_kernel(const u64 *__restrict_
   const u64 *__restrict__ f = filt + (size_t)blockIdx.x * per_filter;
   int nz = 0;
   for (size_t i = threadIdx.x; i < per_filter; i += 256) nz |= red_t(f[i], t) != 0;
-  if (!__syncthreads_or(nz) && threadIdx.x == 0) atomicOr(flag, 1u);
+  if (!__syncthreads_or(nz) && threadIdx.x == 0) *flag = 1u;   // every writer stores the same value: no atomic needed
 }
 
 // share tensor from the RNS mask: out[m][dst] = scale_and_round(r[m*S + slice][coef])
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ 
   if (nzmap && blockIdx.x == 0 && blockIdx.y == 0) {
     int bad = 0;
     for (int m = threadIdx.x; m < M; m += 256) bad |= nzmap[m] == 0;
-    if (bad) atomicOr(zero_filter, 1u);
+    if (bad) *zero_filter = 1u;
   }
   if (fold.wflag) {
     // (the launch after conv_front_kernel: the form is not known yet, so the digits are always written)
@@ -792,7 +792,8 @@ static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, c
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
                              const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1,
-                             const u32 *nzmap = nullptr, u32 *zero_filter = nullptr, const PwFold *fold = nullptr) {
+                             const u32 *nzmap = nullptr, u32 *zero_filter = nullptr, const PwFold *fold = nullptr,
+                             void *verdict_event = nullptr) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const PwSizes z = pw_sizes(p);
@@ -817,6 +818,7 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_chan,
                        p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter,
                        fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0});
+    if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
                        ctx->logN, ctx->d_mods);
@@ -1129,7 +1131,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                             const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share, void *stream,
                             const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr,
                             const mmh_conv_filters *prepared = nullptr, const uint64_t *d_share_raw = nullptr,
-                            uint32_t *d_zero_filter = nullptr, const uint64_t *d_zero_enc = nullptr) {
+                            uint32_t *d_zero_filter = nullptr, const uint64_t *d_zero_enc = nullptr,
+                            void *verdict_event = nullptr) {
   const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
   MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!prepared || prepared->plan == p, MMH_ERR_INVALID_ARG);
@@ -1210,6 +1213,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
       if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
     }
   }
+  // (the verdict is settled here unless the digit kernel of the direct route folds it: recorded there)
+  if (!rc && verdict_event && !nz_inline && hipEventRecord((hipEvent_t)verdict_event, s) != hipSuccess) rc = MMH_ERR_INTERNAL;
   if (!rc && !direct) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
@@ -1218,7 +1223,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                            (u64 *)acc, s, exact, prepared->form);
   if (!rc && front)
     rc = pointwise_product(p, (const u64 *)image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8,
-                           (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold);
+                           (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold,
+                           nz_inline ? verdict_event : nullptr);
   if (!rc && direct && !prepared && !front)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
   if (!rc && !direct && !prepared && d_filters_raw)
@@ -1302,6 +1308,20 @@ extern "C" int mmh_conv_server_tensors(const mmh_conv_plan *p, const uint64_t *d
   return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                           d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr,
                           d_zero_filter);
+}
+
+extern "C" int mmh_conv_server_tensors_ev(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share,
+                                          const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                                          const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                                          uint64_t *d_out_share, uint32_t *zero_filter, void *verdict_event,
+                                          void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
+  MMH_REQUIRE(p && d_filters, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share, MMH_ERR_DIM_MISMATCH);
+  MMH_REQUIRE(!verdict_event || zero_filter, MMH_ERR_INVALID_ARG);
+  return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
+                          d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr,
+                          zero_filter, nullptr, verdict_event);
 }
 
 extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {

@@ -93,6 +93,7 @@ class HomConv2DSS:
     def __init__(self):
         self.ctx = self.sk_ntt = self.pk_ntt = None
         self._plans = {}
+        self._verdicts = None   # page-locked verdict words + events, made on first use
 
     # HomConv2DSS::setUp (hom_conv2d_ss.cc:467-495): sk_ntt [L,N] (client), pk_ntt [2,L,N] (server)
     def setUp(self, ctx, sk_ntt=None, pk_ntt=None):
@@ -219,9 +220,10 @@ class HomConv2DSS:
     def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand, inline_verdict=False, out=None):
         """out: optional (out_cts [n_out,2,1,N], out_share out_shape) buffers to write into instead of fresh ones
         (pre-sized assembly buffers of the sharded form, openmm_amd/sharding.py).
-        inline_verdict: let the layer call evaluate the zero-filter rule itself (one launch less); the verdict
-        is then known only when the whole call has run, so the default checks the filters ahead of the call and
-        waits for that early verdict alone, which lets the host enqueue the next call meanwhile"""
+        The zero-filter rule (conv2DOneFilter :573-580) is evaluated inside the call; by default its verdict is read
+        early, from page-locked memory behind the call's second launch (mmh_conv_server_tensors_ev), so the host
+        raises the reference's error without waiting for the products.  inline_verdict: the older form, the verdict
+        in device memory and read when the whole call has run."""
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
         self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
@@ -232,10 +234,6 @@ class HomConv2DSS:
                        "encodeImage: image shape")
             share_tensor = share_tensor.contiguous()
         filters = filters.contiguous()
-        bad = torch_empty_flag(filters)   # zero-filter verdict
-        if not inline_verdict:
-            L.check(self.ctx.lib.mmh_conv_check_filters(p.handle, L.dptr(filters), L.dptr(bad), L._stream_ptr()))
-            nz = L.DeferredFlag(bad, negate=True)   # true when no filter is all zero
         self._check_rand(p, rand, ("u", "e1", "mask"))
         u, e1, mask = rand
         if out is None:
@@ -245,14 +243,25 @@ class HomConv2DSS:
             out_cts, out_share = out
             self._need(tuple(out_cts.shape) == (p.n_out, 2, 1, self.ctx.N) and tuple(out_share.shape) == p.out_shape,
                        3, "conv2DSS: output buffers")
-        L.check(self.ctx.lib.mmh_conv_server_tensors(p.handle, L.dptr(img_share0),
-                                                     L.dptr(share_tensor if meta.is_shared_input else None),
-                                                     L.dptr(filters), L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
-                                                     L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
-                                                     L.dptr(bad if inline_verdict else None), L._stream_ptr()))
+        share_ptr = L.dptr(share_tensor if meta.is_shared_input else None)
         if inline_verdict:
-            nz = L.DeferredFlag(bad, negate=True)
-        self._need(bool(nz), 8, "conv2DOneFilter: filter with all zero is not supported")
+            bad = torch_empty_flag(filters)   # zero-filter verdict, known when the whole call has run
+            L.check(self.ctx.lib.mmh_conv_server_tensors(p.handle, L.dptr(img_share0), share_ptr, L.dptr(filters),
+                                                         L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),
+                                                         L.dptr(out_cts), L.dptr(out_share), L.dptr(bad),
+                                                         L._stream_ptr()))
+            nz = bool(L.DeferredFlag(bad, negate=True))
+        else:
+            # the verdict lands in page-locked memory behind the call's second launch; wait for that point alone
+            if self._verdicts is None:
+                self._verdicts = L.VerdictRing()
+            slot, word, event = self._verdicts.take()
+            L.check(self.ctx.lib.mmh_conv_server_tensors_ev(p.handle, L.dptr(img_share0), share_ptr, L.dptr(filters),
+                                                            L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),
+                                                            L.dptr(out_cts), L.dptr(out_share), word, event,
+                                                            L._stream_ptr()))
+            nz = self._verdicts.read(slot) == 0   # true when no filter is all zero
+        self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
         return out_cts, out_share
 
     # static weights: encode once per model, then conv2DSSPrepared per inference (same bits as

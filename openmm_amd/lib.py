@@ -98,6 +98,11 @@ SIGNATURES = {
     "mmh_reduce_mod_t": [_vp, _vp, _vp, _sz, _vp],
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server_tensors": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server_tensors_ev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_event_create": [C.POINTER(_vp)],
+    "mmh_event_destroy": [_vp],
+    "mmh_event_record": [_vp, _vp],
+    "mmh_event_sync": [_vp],
     "mmh_conv_check_filters": [_vp, _vp, _vp, _vp],
     "mmh_conv_filters_prepare": [_vp, _vp, C.POINTER(_vp), _vp],
     "mmh_conv_filters_destroy": [_vp],
@@ -199,6 +204,40 @@ class DeferredFlag:
     def __bool__(self):
         self.event.synchronize()
         return bool(self.host) != self.negate
+
+
+class VerdictRing:
+    """Page-locked words the kernels store early verdicts into, each with an event recorded right behind the launch
+    that settles it (mmh_conv_server_tensors_ev): the host waits for that event alone.  A ring, so that a slot is
+    not reused while a call that writes it may still be in flight (callers read their verdict before they return)."""
+
+    def __init__(self, slots=32):
+        import torch
+        self.lib = load_library()
+        self.words = torch.zeros(slots, dtype=torch.int32, pin_memory=True)
+        self.base = self.words.data_ptr()
+        self.events = []
+        for _ in range(slots):
+            e = _vp()
+            check(self.lib.mmh_event_create(C.byref(e)))
+            self.events.append(e)
+        self.next = 0
+
+    def take(self):
+        i = self.next
+        self.next = (i + 1) % len(self.events)
+        return i, _vp(self.base + 4 * i), self.events[i]
+
+    def read(self, i):
+        check(self.lib.mmh_event_sync(self.events[i]))
+        return int(self.words[i])
+
+    def __del__(self):
+        try:
+            for e in self.events:
+                self.lib.mmh_event_destroy(e)
+        except Exception:
+            pass
 
 
 def dptr(t):
