@@ -674,17 +674,32 @@ extern "C" int mmh_truncate_and_zero(const mmh_ctx *ctx, uint64_t *d_cts, size_t
 // truncates, clears the unused coefficients and (d_share_dst [keep_period][N]: target index or -1) scatters
 // the mask's scale-and-round into the share tensor d_share_out [n / keep_period][share_plane].  Same bits as the step-by-step entry points.
 namespace mmh {
+int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
+                          const int64_t *d_u, const u64 *d_u_ntt, const int64_t *d_e1, const u64 *d_mask,
+                          const uint8_t *d_keep, size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst,
+                          size_t share_plane, u64 *d_share_out);
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
                         const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
                         u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out) {
+  return reshare_tail_approx_u(ctx, d_acc, acc_ntt_form, n, d_pk_ntt_last, d_u, nullptr, d_e1, d_mask, d_keep,
+                               keep_period, d_out, s, d_share_dst, share_plane, d_share_out);
+}
+// d_u_ntt: u already transformed (the front launch of a direct-route layer does it beside its own work), else null
+int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
+                          const int64_t *d_u, const u64 *d_u_ntt, const int64_t *d_e1, const u64 *d_mask,
+                          const uint8_t *d_keep, size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst,
+                          size_t share_plane, u64 *d_share_out) {
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   const size_t N = ctx->N;
   StreamBuf u(s);
-  MMH_HIP(u.alloc(n * N * 8));
+  if (!d_u_ntt) MMH_HIP(u.alloc(n * N * 8));
   if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
-  CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
+  if (!d_u_ntt) {
+    CHECK_RC(ntt_signed_dispatch(ctx, d_u, u.as<u64>(), n, 1, s));
+    d_u_ntt = u.as<u64>();
+  }
   // Few output ciphertexts: the fused kernel has one workgroup per component and walks its coefficients in four
   // batches, each a memory round trip, so below the size where it fills the chip the encryption of zero is written
   // out and the tail runs one thread per coefficient instead; same bits.  Measured per layer call (GPU time, fused
@@ -695,13 +710,13 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   if (n <= split_max) {
     StreamBuf z(s);
     MMH_HIP(z.alloc(n * 2 * N * 8));
-    CHECK_RC(ntt_inv_product_dispatch(ctx, u.as<u64>(), d_pk_ntt_last, z.as<u64>(), n, 1, s));
+    CHECK_RC(ntt_inv_product_dispatch(ctx, d_u_ntt, d_pk_ntt_last, z.as<u64>(), n, 1, s));
     return reshare_online_dispatch(ctx, z.as<u64>(), n, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst,
                                    share_plane, d_share_out, s);
   }
   // u * pk_j back to coefficient form and, coefficient by coefficient, into the tail (ReshareSink, ntt.hip): the
   // encryption of zero is never written
-  CHECK_RC(ntt_inv_product_reshare(ctx, u.as<u64>(), d_pk_ntt_last, n, d_acc, d_e1, d_mask, d_out, d_keep,
+  CHECK_RC(ntt_inv_product_reshare(ctx, d_u_ntt, d_pk_ntt_last, n, d_acc, d_e1, d_mask, d_out, d_keep,
                                    keep_period, d_share_dst, share_plane, d_share_out, s));
   return MMH_OK;
 }

@@ -5,6 +5,7 @@
 #include "bfv_device.hpp"
 #include "common.hpp"
 #include "geometry.hpp"
+#include "ntt_device.hpp"
 
 #include <cstdlib>
 
@@ -16,6 +17,11 @@ int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last, const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
                         u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out);
+// (d_u_ntt: u already in NTT form at the last level, or null)
+int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
+                          const int64_t *d_u, const u64 *d_u_ntt, const int64_t *d_e1, const u64 *d_mask,
+                          const uint8_t *d_keep, size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst,
+                          size_t share_plane, u64 *d_share_out);
 int reshare_tail_online(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_zero,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period, u64 *d_out,
                         hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out);
@@ -319,16 +325,27 @@ __global__ __launch_bounds__(256) void pw_weights_kernel(PwWeightArgs a, u32 *__
 // add_plain), the others the weight forms.  Nothing here needs a cleared word: every weights workgroup leaves its flag
 // bits in a word of its own (wflag) and every thread its "has a non-zero weight" byte (anymap, [taps / 16][Mpad128]);
 // pw_expand_kernel, the next launch, folds them into the one flag word and the zero-filter verdict.
+// Workgroups [0, n_u) beside them transform the ternary u of the re-sharing tail (encrypt_zero's first step,
+// hom_conv2d_ss.cc:302-306), which depends on nothing else in the call: for the small layers of a network its launch
+// was a tenth of the call.
+template <int LOGN>
 __global__ __launch_bounds__(256) void conv_front_kernel(ImageShareArgs ia, BfvConsts b, const DevMod *__restrict__ mods,
-                                                         unsigned n_img, PwWeightArgs wa, u32 *__restrict__ wflag,
-                                                         uint8_t *__restrict__ anymap, u32 *__restrict__ zero_filter) {
-  if (blockIdx.x < n_img) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                         unsigned n_u, unsigned n_img, PwWeightArgs wa,
+                                                         u32 *__restrict__ wflag, uint8_t *__restrict__ anymap,
+                                                         u32 *__restrict__ zero_filter, u64 *__restrict__ u_ntt,
+                                                         NttSource usrc, const ulonglong2 *__restrict__ tables) {
+  extern __shared__ __align__(16) u64 front_lds[];
+  if (blockIdx.x < n_u) {
+    ntt_fwd_unit<LOGN, true, SRC_SIGNED>(blockIdx.x, u_ntt, mods, tables, 1, 0, usrc, front_lds);
+    return;
+  }
+  if (blockIdx.x < n_u + n_img) {
+    const size_t idx = (size_t)(blockIdx.x - n_u) * 256 + threadIdx.x;
     if (idx == 0 && zero_filter) *zero_filter = 0;
     image_plus_share_body(idx, ia, b, mods);
     return;
   }
-  const unsigned wb = blockIdx.x - n_img;
+  const unsigned wb = blockIdx.x - n_u - n_img;
   const size_t gid = (size_t)wb * 256 + threadIdx.x;
   const u32 r = pw_weights_body<false>(gid, wa);
   if (anymap && gid < (size_t)(wa.Cpad64 / 16) * wa.Mpad128) anymap[gid] = (uint8_t)((r >> 2) & 1u);
@@ -1147,12 +1164,13 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   const size_t N = ctx->N, M = (size_t)p->meta.n_filters, S = p->n_spatial, Cs = p->n_cslices;
   void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr, *mask_t = nullptr;
   void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *anymap = nullptr;   // weight forms of a fresh direct-route call
+  void *u_ntt = nullptr;                                                  // u of the tail, transformed by the front launch
   void *flag_word = nullptr;   // the direct route's weight-form flag, cleared by the kernel that builds the image
   // the route: prepared filters carry the one they were prepared for
   const bool direct = prepared ? prepared->w8 != nullptr : p->direct_fresh;
   int rc = MMH_OK;
   auto cleanup = [&]() {
-    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word, wp, wl, w8, anymap})
+    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word, wp, wl, w8, anymap, u_ntt})
       if (b) (void)scratch_free(b, s);
   };
   auto grab = [&](void **b, size_t bytes) {
@@ -1183,10 +1201,30 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     if (nz_inline) grab(&anymap, (size_t)(z.Cpad64 / 16) * z.Mpad128);
     if (!rc) {
       fold = PwFold{(const u32 *)flag_word + 1, (int)n_w, (u32 *)flag_word, (const uint8_t *)anymap, z.Cpad64 / 16, z.Mpad128};
-      hipLaunchKernelGGL(conv_front_kernel, dim3(n_img + n_w), dim3(256), 0, s, img_args, ctx->bfv, ctx->d_mods, n_img,
-                         pw_weight_args(p, d_filters_raw, (u32 *)wp, (u64 *)wl, (uint8_t *)w8), (u32 *)flag_word + 1,
-                         (uint8_t *)anymap, d_zero_filter);
-      if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+      // u's transform rides along when the tail will want it (approximate build, q0 of the folding shape)
+      const bool with_u = !exact && !d_zero_enc && ctx->h_mods[0].fold_c != 0 && !ctx->h_mods[0].f64;
+      if (with_u) grab(&u_ntt, p->n_out * N * 8);
+      const unsigned n_u = with_u && !rc ? (unsigned)p->n_out : 0;
+      NttSource usrc{};
+      usrc.p = reinterpret_cast<const u64 *>(d_u);
+      const PwWeightArgs wa = pw_weight_args(p, d_filters_raw, (u32 *)wp, (u64 *)wl, (uint8_t *)w8);
+      if (!rc && ctx->logN == 12)
+        hipLaunchKernelGGL(conv_front_kernel<12>, dim3(n_u + n_img + n_w), dim3(256), lds_bytes<12>(), s, img_args, ctx->bfv,
+                           ctx->d_mods, n_u, n_img, wa, (u32 *)flag_word + 1, (uint8_t *)anymap, d_zero_filter,
+                           (u64 *)u_ntt, usrc, ctx->d_tables);
+      else if (!rc && ctx->logN == 13) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_front_kernel<13>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<13>()) != hipSuccess)
+          rc = MMH_ERR_INTERNAL;
+        if (!rc)
+          hipLaunchKernelGGL(conv_front_kernel<13>, dim3(n_u + n_img + n_w), dim3(256), lds_bytes<13>(), s, img_args,
+                             ctx->bfv, ctx->d_mods, n_u, n_img, wa, (u32 *)flag_word + 1, (uint8_t *)anymap,
+                             d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables);
+      } else if (!rc) {
+        rc = MMH_ERR_CONFIG;
+      }
+      if (!rc && hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+      if (!n_u && u_ntt) (void)scratch_free(u_ntt, s), u_ntt = nullptr;
     }
   } else if (!rc && via_image_kernel) {
     const int n_words = direct && !prepared ? 1 : 0;
@@ -1242,8 +1280,9 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     rc = d_zero_enc
              ? reshare_tail_online(ctx, (u64 *)acc, !direct, p->n_out, d_zero_enc, d_e1, d_mask, p->d_keep, S, d_out_cts,
                                    s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share)
-             : reshare_tail_approx(ctx, (u64 *)acc, !direct, p->n_out, d_pk_ntt_last, d_u, d_e1, d_mask, p->d_keep, S,
-                                   d_out_cts, s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share);
+             : reshare_tail_approx_u(ctx, (u64 *)acc, !direct, p->n_out, d_pk_ntt_last, d_u, (const u64 *)u_ntt, d_e1,
+                                     d_mask, p->d_keep, S, d_out_cts, s, p->d_share_dst,
+                                     (size_t)(p->out_h * p->out_w), d_out_share);
   }
   if (exact) {
     // USE_APPROX_RESHARE=0: uniform noise on c0 first, e0 kept, the mask is a plaintext mod t subtracted
