@@ -18,9 +18,9 @@
 //     above the largest multiple of q redrawn from the same stream);
 //   * parms_id = BLAKE2b-256 over the words {scheme, N, n_special_primes, q_0 .. q_{L-1}, t}.
 // Compression: this writer emits compr_mode none, which every SEAL build loads.  An unmodified reference party writes
-// compr_mode zstd (SEAL's default when built with it); reading that needs a zstd decoder, which this image does not
-// have as a C library -- such a stream is refused with a message that says so.  PublicKey::save is Ciphertext::save
-// of its data.
+// compr_mode zstd (SEAL's default when built with it): the loader inflates it with the decoder of
+// seal/zstd_decode.h (libzstd is not in this image as a C library; the decoder is checked against the libzstd inside
+// pyarrow).  zlib streams are refused with a message that says so.  PublicKey::save is Ciphertext::save of its data.
 #pragma once
 #include <array>
 #include <cstdint>
@@ -30,6 +30,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "seal/zstd_decode.h"
 
 namespace seal {
 namespace wire {
@@ -273,8 +275,8 @@ struct Reader {
     std::memcpy(dst, p, n);
     p += n;
   }
-  // one SEALHeader; returns the bytes that follow it inside its object
-  std::size_t header() {
+  // one SEALHeader; returns the bytes that follow it inside its object and the object's compr_mode
+  std::size_t header(std::uint8_t *compr_mode = nullptr) {
     need(kHeaderBytes);
     const std::uint16_t magic = u16();
     const std::uint8_t hsize = u8(), vmaj = u8(), vmin = u8(), compr = u8();
@@ -282,10 +284,13 @@ struct Reader {
     const std::uint64_t total = u64();
     if (magic != kMagic || hsize != 0x10) throw std::logic_error("seal wire: not a SEAL object (bad header)");
     if (vmaj != 3 || (vmin != 6 && vmin != 7)) throw std::logic_error("seal wire: SEAL version other than 3.6 / 3.7");
-    if (compr == compr_zstd || compr == compr_zlib)
-      throw std::logic_error("seal wire: compressed stream (compr_mode " + std::to_string(compr) +
-                             "): no zstd / zlib decoder in this build; the peer must save with compr_mode_type::none");
-    if (compr != compr_none) throw std::logic_error("seal wire: unknown compr_mode");
+    if (compr == compr_zlib)
+      throw std::logic_error("seal wire: compressed stream (compr_mode zlib): no zlib decoder in this build; the peer "
+                             "must save with compr_mode_type::zstd or none");
+    if (compr != compr_none && compr != compr_zstd) throw std::logic_error("seal wire: unknown compr_mode");
+    if (compr == compr_zstd && !compr_mode)
+      throw std::logic_error("seal wire: compressed stream (compr_mode zstd) where SEAL writes none");
+    if (compr_mode) *compr_mode = compr;
     if (total < kHeaderBytes) throw std::logic_error("seal wire: size field below the header size");
     need(total - kHeaderBytes);
     return (std::size_t)total - kHeaderBytes;
@@ -329,8 +334,23 @@ inline std::string save_ciphertext(const CtMeta &m, const std::uint64_t *data, c
 // receives size * N * L words; for a seeded object the second polynomial is left for the caller to expand.
 inline std::size_t load_ciphertext(const std::uint8_t *bytes, std::size_t n, CtMeta &m, std::vector<std::uint64_t> &data,
                                    bool &seeded, std::uint8_t (&seed)[kSeedBytes], std::size_t *consumed = nullptr) {
-  Reader r{bytes, bytes + n};
-  const std::size_t body = r.header();
+  Reader outer{bytes, bytes + n};
+  std::uint8_t compr = compr_none;
+  std::size_t body = outer.header(&compr);
+  if (consumed) *consumed = kHeaderBytes + body;
+  // SEAL's default: the members behind the header are one Zstandard stream (the objects nested inside are saved with
+  // compr_mode none); inflate it and read the members from the result
+  std::vector<std::uint8_t> inflated;
+  Reader r{outer.p, outer.p + body};
+  if (compr == compr_zstd) {
+    try {
+      inflated = zstd::decompress(outer.p, body, (std::size_t)1 << 28);
+    } catch (const zstd::Error &e) {
+      throw std::logic_error(std::string("seal wire: ") + e.what());
+    }
+    r = Reader{inflated.data(), inflated.data() + inflated.size()};
+    body = inflated.size();
+  }
   const std::uint8_t *obj_end = r.p + body;
   if (body < kCtMemberBytes) throw std::logic_error("seal wire: ciphertext members missing");
   for (int i = 0; i < 4; ++i) m.parms_id[i] = r.u64();
@@ -358,7 +378,6 @@ inline std::size_t load_ciphertext(const std::uint8_t *bytes, std::size_t n, CtM
     r.raw(seed, kSeedBytes);
   }
   if (r.p != obj_end) throw std::logic_error("seal wire: ciphertext object size mismatch");
-  if (consumed) *consumed = (std::size_t)(r.p - bytes);
   return (std::size_t)words;
 }
 

@@ -5,6 +5,7 @@
 //   wire_tool uniform  HEXSEED N Q...              words of sample_poly_uniform, hex, one per line
 //   wire_tool save     SEEDED NTT SIZE N HEXSEED T Q...   a ciphertext with data[i] = f(i) mod q_l, SEAL bytes as hex
 //   wire_tool load     < hex on stdin              prints the members and a checksum of the words (c1 expanded if seeded)
+//   wire_tool inflate  < hex on stdin              Zstandard frames -> content, hex
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +98,12 @@ int main(int argc, char **argv) {
       std::uint64_t sum = 0;
       for (std::size_t i = 0; i < words; ++i) sum = sum * 0x100000001B3ull + data[i];
       std::printf("checksum %016" PRIx64 "\n", sum);
+    } else if (cmd == "inflate") {   // hex of Zstandard frames on stdin -> hex of the content
+      std::string h;
+      std::cin >> h;
+      const auto bytes = unhex(h);
+      const auto out = zstd::decompress(bytes.data(), bytes.size());
+      hex(out.data(), out.size());
     } else {
       return 2;
     }

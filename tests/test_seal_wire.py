@@ -5,7 +5,9 @@ reference tree and no serialised object is either); what can be pinned here is p
   * BLAKE2xb: the root hash against hashlib (which accepts its parameters), the output blocks against a pure-Python
     BLAKE2b that is itself checked against hashlib (hashlib refuses their depth = 0);
   * the byte layout against a second, independent statement of it in this file (struct.pack), sizes included;
-  * save -> load round trips, the seeded form's expansion, and the refusal of compressed streams.
+  * save -> load round trips, the seeded form's expansion;
+  * the Zstandard decoder (include/seal/zstd_decode.h) against the libzstd inside pyarrow, and a ciphertext object
+    compressed the way SEAL's default save() compresses it.
 Host code only: the tool is compiled with g++ here, no device library involved."""
 import hashlib
 import os
@@ -227,13 +229,92 @@ def test_ciphertext_layout_and_round_trip(tool, q, N, ntt):
             assert out[2] == seed.hex()
 
 
+def zstd_inputs():
+    """inputs that walk the decoder's branches: raw / RLE / compressed blocks, Huffman literals with direct and
+    FSE-compressed weights, one and four streams, repeat offsets, long matches, several blocks per frame"""
+    import numpy as np
+    rng = np.random.default_rng(0x4D264D)
+    yield "empty", b""
+    yield "one byte", b"x"
+    yield "random 1000 (raw block)", rng.bytes(1000)
+    yield "zeros 100000 (RLE)", bytes(100000)
+    yield "text", (b"the quick brown fox jumps over the lazy dog. " * 300)[:12345]
+    yield "skewed bytes (Huffman, few symbols)", bytes(rng.choice([0, 1, 2, 3, 250], size=5000, p=[.6, .2, .1, .05, .05]).astype(np.uint8))
+    yield "skewed bytes 200 KiB (several blocks, four streams)", bytes(rng.geometric(0.08, size=200 * 1024).astype(np.uint8))
+    yield "many symbols (FSE-compressed weights)", bytes(np.clip(rng.normal(128, 30, size=60000), 0, 255).astype(np.uint8))
+    yield "repeats with gaps", b"".join(bytes([i % 7]) * (i % 50) + b"abcdefgh" for i in range(3000))
+    words = rng.integers(0, 1 << 60, size=2 * 4096, dtype=np.uint64)
+    yield "ciphertext words", words.tobytes()
+    trunc = (words >> np.uint64(23)) << np.uint64(23)
+    trunc[4096 + 200:] = 0
+    yield "truncated ciphertext (cleared low bits, removed coefficients)", trunc.tobytes()
+    yield "1.5 MiB mixed", b"".join([rng.bytes(300000), bytes(500000), (b"0123456789" * 70000)[:600000],
+                                    bytes(rng.geometric(0.3, size=100000).astype(np.uint8))])
+
+
+def test_zstd_decoder_against_libzstd(tool):
+    """the decoder of include/seal/zstd_decode.h against the libzstd inside pyarrow: one-shot frames (content size in
+    the header) at several levels and streaming frames (no content size, as SEAL's writer produces them)"""
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("zstd"):
+        pytest.skip("pyarrow built without zstd")
+    for name, data in zstd_inputs():
+        for level in (1, 3, 9, 19):
+            z = pa.Codec("zstd", compression_level=level).compress(data, asbytes=True)
+            got = tool("inflate", stdin=z.hex() or "00")[0] if z else ""
+            assert bytes.fromhex(got) == data, (name, level)
+        sink = pa.BufferOutputStream()
+        with pa.CompressedOutputStream(sink, "zstd") as f:
+            for i in range(0, len(data), 70000):
+                f.write(data[i:i + 70000])
+        z = sink.getvalue().to_pybytes()
+        if z:
+            assert bytes.fromhex(tool("inflate", stdin=z.hex())[0]) == data, (name, "stream")
+        # two frames back to back decode to the concatenation
+        if data and len(data) < 20000:
+            z2 = pa.Codec("zstd").compress(data, asbytes=True) * 2
+            assert bytes.fromhex(tool("inflate", stdin=z2.hex())[0]) == data * 2, (name, "two frames")
+    out = tool("inflate", stdin=pa.Codec("zstd").compress(b"abc" * 100, asbytes=True)[:-3].hex(), ok=False)
+    assert out[0].startswith("error: zstd")
+
+
+@pytest.mark.parametrize("seeded", [0, 1])
+def test_ciphertext_saved_with_seals_default_compression_loads(tool, seeded):
+    """what an unmodified reference party sends: SEALHeader with compr_mode zstd, then the members as one Zstandard
+    stream (nested objects uncompressed inside it)"""
+    pa = pytest.importorskip("pyarrow")
+    q, N = (Q0, Q1), 4096
+    seed = bytes(range(64))
+    plain, data = py_ciphertext(q, T, N, 2, 0, seed if seeded else None)
+    sink = pa.BufferOutputStream()
+    with pa.CompressedOutputStream(sink, "zstd") as f:
+        f.write(plain[16:])
+    z = sink.getvalue().to_pybytes()
+    obj = py_header(16 + len(z), compr=2) + z
+    out = tool("load", stdin=obj.hex())
+    ref = tool("load", stdin=plain.hex())
+    assert out[0] == ref[0] and out[-1] == ref[-1]
+    f = out[1].split()
+    assert int(f[f.index("consumed") + 1]) == len(obj) and f[f.index("seeded") + 1] == str(seeded)
+    # a truncated-for-decryption result compresses, and still loads to the same words
+    import numpy as np
+    words = (np.frombuffer(plain[16 + 73 + 24:16 + 73 + 24 + 8 * 2 * N], dtype=np.uint64) >> np.uint64(20)) << np.uint64(20)
+    if not seeded:
+        body = plain[16:16 + 73 + 24] + words.tobytes() + plain[16 + 73 + 24 + 8 * 2 * N:]
+        z = pa.Codec("zstd").compress(body, asbytes=True)
+        assert len(z) < len(body) * 0.9
+        out = tool("load", stdin=(py_header(16 + len(z), compr=2) + z).hex())
+        assert out[1].split()[1::2][:4] == ["0", "2", str(N), "2"]
+
+
 def test_compressed_and_damaged_streams_are_refused(tool):
     want, _ = py_ciphertext((Q0,), T, 64, 2, 0)
-    for compr, word in ((2, "zstd"), (1, "zlib")):
-        bad = bytearray(want)
-        bad[5] = compr
-        out = tool("load", stdin=bytes(bad).hex(), ok=False)
-        assert "compressed stream" in out[0] and "decoder" in out[0]
+    bad = bytearray(want)
+    bad[5] = 1      # zlib: no decoder
+    out = tool("load", stdin=bytes(bad).hex(), ok=False)
+    assert "compressed stream" in out[0] and "zlib" in out[0]
+    bad[5] = 2      # marked zstd, but the bytes behind the header are no Zstandard frame
+    assert "zstd" in tool("load", stdin=bytes(bad).hex(), ok=False)[0]
     for mutate in (lambda b: b[:-8], lambda b: b[:100], lambda b: b"\x00" + b[1:]):
         out = tool("load", stdin=bytes(mutate(bytes(want))).hex(), ok=False)
         assert out[0].startswith("error:")
