@@ -644,6 +644,8 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
   const size_t cols = S * 4 * N, c0 = (size_t)tile * 64;
   const size_t col = c0 + wn * 16 + (lane & 15);
   const int mrow = mt * 128 + wm * 64 + (lane >> 4) * 4;   // + 16*ms + r
+  // 16-filter tiles of this wave that hold a filter at all (wave-uniform; 4 except in the layer's last 128-filter tile)
+  const int ms_used = __builtin_amdgcn_readfirstlane(min(4, max(0, (M - (mt * 128 + wm * 64) + 15) / 16)));
   const int l = (int)((c0 >> logN) & 1);
   const DevMod q = mods[l];             // for the epilogue; loaded here so that its latency hides behind the products
   const uint4 *__restrict__ gB = u8 + (size_t)slot * KC * 2048 + lane;
@@ -703,6 +705,7 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
     }
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms) {
+      if (ms >= ms_used) break;   // filter tiles past the layer's last filter (layers with few filters): no products
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         if (a < nA) {
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
   for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (ms >= ms_used) continue;
       u32 p[10];
 #pragma unroll
       for (int d = 0; d < 10; ++d) p[d] = (u32)sum[ms][d][r];

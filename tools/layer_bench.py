@@ -8,6 +8,9 @@ import torch
 import openmm_amd
 from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
 
+if os.environ.get("MMH_LIB"):   # A/B of library builds (tools/exp/build_variant.sh)
+    import openmm_amd.lib as _L0
+    _L0.LIB_PATH = os.path.abspath(os.environ["MMH_LIB"])
 if os.environ.get("NO_VERDICT_WAIT"):   # host enqueue cost alone: never wait for the zero-filter verdict
     import openmm_amd.lib as _L
     _L.DeferredFlag.__bool__ = lambda self: True
