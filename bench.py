@@ -335,7 +335,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=5, convs=None
             # static weights prepared once per model (not what the reference does: reported apart)
             prep = srv.prepareFilters(filters, meta)
             cached_total += count * wall_ms(lambda: srv.conv2DSSPrepared(
-                cts, srv.encodeImage(share, meta) if shared else None, prep, meta, rand))
+                cts, None, prep, meta, rand, share_tensor=share if shared else None))
             # ... and with the input-independent encryptions of zero of the re-sharing made ahead as well (offline
             # phase; fresh ones are needed per inference, their making is timed apart)
             zeros = srv.prepareZeros(meta, rand[0])

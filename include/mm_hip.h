@@ -373,6 +373,12 @@ int mmh_conv_server_online(const mmh_conv_plan *plan, const uint64_t *d_in_cts, 
                            const uint64_t *d_share_raw, const mmh_conv_filters *filters, const uint64_t *d_zero,
                            const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts, uint64_t *d_out_share,
                            void *stream);
+/* mmh_conv_server_prepared with the server's share as the raw tensor [C][H][W] (encodeImage, hom_conv2d_ss.cc:524-545,
+ * fused into the call the way mmh_conv_server_tensors does it); same bits. */
+int mmh_conv_server_prepared_tensors(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share,
+                                     const mmh_conv_filters *filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
+                                     const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
+                                     uint64_t *d_out_share, void *stream);
 /* Compact wire form of conv2DSS's result ciphertexts [n_out][2][N] (last level).  The reference sends them through
  * seal::Ciphertext::save (cheetah-api.cpp:11-29, :443-444), whose compression squeezes out what
  * truncate_for_decryption (hom_conv2d_ss.cc:418-436) and remove_unused_coeffs (:800-851) zeroed; this pair does it

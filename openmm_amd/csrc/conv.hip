@@ -1192,19 +1192,23 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                                 p->sub_h, p->sub_w};
   // the front of a fresh direct-route call from the raw tensors is one launch (conv_front_kernel): image and weight
   // forms side by side, flag bits and the zero-filter map left for the digit kernel to fold
-  const bool front = via_image_kernel && direct && !prepared && d_filters_raw && pw_mfma_enabled(ctx);
-  const bool nz_inline = d_zero_filter && front;
+  // (with prepared filters the launch has no weight part: image and u's transform)
+  const bool front = via_image_kernel && direct && (prepared || d_filters_raw) && pw_mfma_enabled(ctx);
+  const bool nz_inline = d_zero_filter && front && !prepared;
   PwFold fold{nullptr, 0, nullptr, nullptr, 0, 0};
   if (!rc && front) {
     const PwSizes z = pw_sizes(p);
-    const unsigned n_img = nblk(p->n_in << ctx->logN), n_w = nblk((size_t)(z.Cpad64 / 16) * z.Mpad128);
-    grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
-    grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
-    grab(&w8, z.w8_bytes());
-    grab(&flag_word, 4 * (size_t)(1 + n_w));              // the folded word, then one word per weights workgroup
+    const unsigned n_img = nblk(p->n_in << ctx->logN), n_w = prepared ? 0 : nblk((size_t)(z.Cpad64 / 16) * z.Mpad128);
+    if (!prepared) {
+      grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
+      grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
+      grab(&w8, z.w8_bytes());
+      grab(&flag_word, 4 * (size_t)(1 + n_w));              // the folded word, then one word per weights workgroup
+    }
     if (nz_inline) grab(&anymap, (size_t)(z.Cpad64 / 16) * z.Mpad128);
     if (!rc) {
-      fold = PwFold{(const u32 *)flag_word + 1, (int)n_w, (u32 *)flag_word, (const uint8_t *)anymap, z.Cpad64 / 16, z.Mpad128};
+      if (!prepared)
+        fold = PwFold{(const u32 *)flag_word + 1, (int)n_w, (u32 *)flag_word, (const uint8_t *)anymap, z.Cpad64 / 16, z.Mpad128};
       // u's transform rides along when the tail will want it (approximate build, q0 of the folding shape)
       const bool with_u = !exact && !d_zero_enc && ctx->h_mods[0].fold_c != 0 && !ctx->h_mods[0].f64;
       if (with_u) grab(&u_ntt, p->n_out * N * 8);
@@ -1214,16 +1218,16 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
       const PwWeightArgs wa = pw_weight_args(p, d_filters_raw, (u32 *)wp, (u64 *)wl, (uint8_t *)w8);
       if (!rc && ctx->logN == 12)
         hipLaunchKernelGGL(conv_front_kernel<12>, dim3(n_u + n_img + n_w), dim3(256), lds_bytes<12>(), s, img_args, ctx->bfv,
-                           ctx->d_mods, n_u, n_img, wa, (u32 *)flag_word + 1, (uint8_t *)anymap, d_zero_filter,
-                           (u64 *)u_ntt, usrc, ctx->d_tables);
+                           ctx->d_mods, n_u, n_img, wa, flag_word ? (u32 *)flag_word + 1 : nullptr, (uint8_t *)anymap,
+                           d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables);
       else if (!rc && ctx->logN == 13) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_front_kernel<13>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<13>()) != hipSuccess)
           rc = MMH_ERR_INTERNAL;
         if (!rc)
           hipLaunchKernelGGL(conv_front_kernel<13>, dim3(n_u + n_img + n_w), dim3(256), lds_bytes<13>(), s, img_args,
-                             ctx->bfv, ctx->d_mods, n_u, n_img, wa, (u32 *)flag_word + 1, (uint8_t *)anymap,
-                             d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables);
+                             ctx->bfv, ctx->d_mods, n_u, n_img, wa, flag_word ? (u32 *)flag_word + 1 : nullptr,
+                             (uint8_t *)anymap, d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables);
       } else if (!rc) {
         rc = MMH_ERR_CONFIG;
       }
@@ -1263,7 +1267,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && direct && prepared)
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
                            (u64 *)acc, s, exact, prepared->form);
-  if (!rc && front)
+  if (!rc && front && !prepared)
     rc = pointwise_product(p, (const u64 *)image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8,
                            (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold,
                            nz_inline ? verdict_event : nullptr);
@@ -1428,6 +1432,18 @@ extern "C" int mmh_conv_server_prepared(const mmh_conv_plan *p, const uint64_t *
   MMH_REQUIRE(filters, MMH_ERR_NULL_POINTER);
   return conv_server_impl(p, d_in_cts, d_share_pts, nullptr, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                           d_out_share, stream, nullptr, nullptr, filters);
+}
+
+// mmh_conv_server_prepared from the raw share tensor (encodeImage fused into the call, as _tensors does)
+extern "C" int mmh_conv_server_prepared_tensors(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share,
+                                                const mmh_conv_filters *filters, const uint64_t *d_pk_ntt_last,
+                                                const int64_t *d_u, const int64_t *d_e1, const uint64_t *d_mask,
+                                                uint64_t *d_out_cts, uint64_t *d_out_share, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
+  MMH_REQUIRE(p && filters, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share, MMH_ERR_DIM_MISMATCH);
+  return conv_server_impl(p, d_in_cts, nullptr, nullptr, nullptr, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts, d_out_share,
+                          stream, nullptr, nullptr, filters, p->meta.is_shared_input ? d_share : nullptr);
 }
 
 // The online half of a layer whose weights and whose encryptions of zero were prepared ahead of the inputs

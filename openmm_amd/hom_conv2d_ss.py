@@ -273,24 +273,28 @@ class HomConv2DSS:
         self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
         return PreparedFilters(self.plan(meta), filters, nz)
 
-    def conv2DSSPrepared(self, img_share0, img_share1, prepared, meta, rand):
+    def conv2DSSPrepared(self, img_share0, img_share1, prepared, meta, rand, share_tensor=None):
+        """share_tensor: the server's share as the raw tensor instead of its encoding img_share1 (encodeImage fused
+        into the call)"""
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         p = self.plan(meta)
         self._need(prepared.plan is p, 7, "conv2DSS: filters prepared for another layer")
         self._need(tuple(img_share0.shape) == (p.n_in, 2, self.ctx.L, self.ctx.N), 3, "conv2DSS: #ciphertexts")
-        if meta.is_shared_input:
+        raw = share_tensor is not None
+        if meta.is_shared_input and raw:
+            self._need(img_share1 is None and tuple(share_tensor.shape) == tuple(meta.ishape), 3, "encodeImage: image shape")
+            share_tensor = share_tensor.contiguous()
+        elif meta.is_shared_input:
             self._need(img_share1 is not None and img_share1.shape[0] == img_share0.shape[0], 3, "conv2DSS: #shares")
-        self._check_rand(p, rand, ("u", "e1", "mask"))
-        if meta.is_shared_input:
             self._need(tuple(img_share1.shape) == (p.n_in, self.ctx.N), 3, "conv2DSS: share plaintexts shape")
+        self._check_rand(p, rand, ("u", "e1", "mask"))
         u, e1, mask = rand
         out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
         out_share = self.ctx._empty(*p.out_shape)
-        L.check(self.ctx.lib.mmh_conv_server_prepared(p.handle, L.dptr(img_share0),
-                                                      L.dptr(img_share1 if meta.is_shared_input else None),
-                                                      prepared.handle, L.dptr(self.pk_last), L.dptr(u), L.dptr(e1),
-                                                      L.dptr(mask), L.dptr(out_cts), L.dptr(out_share),
-                                                      L._stream_ptr()))
+        fn = self.ctx.lib.mmh_conv_server_prepared_tensors if raw else self.ctx.lib.mmh_conv_server_prepared
+        share = (share_tensor if raw else img_share1) if meta.is_shared_input else None
+        L.check(fn(p.handle, L.dptr(img_share0), L.dptr(share), prepared.handle, L.dptr(self.pk_last), L.dptr(u),
+                   L.dptr(e1), L.dptr(mask), L.dptr(out_cts), L.dptr(out_share), L._stream_ptr()))
         return out_cts, out_share
 
     # the re-sharing tail split at the point where the input enters it (include/mm_hip.h): the encryptions of zero

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mmh_conv_filters_prepare": [_vp, _vp, C.POINTER(_vp), _vp],
     "mmh_conv_filters_destroy": [_vp],
     "mmh_conv_server_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server_prepared_tensors": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_reshare_zero_prepare": [_vp, _vp, _vp, _sz, _vp, _vp],
     "mmh_conv_server_online": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],

@@ -152,6 +152,9 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
         pre_out, pre_share = server.conv2DSSPrepared(got_cts, got_s, prep, meta, (dev(u), dev(e1), dev(mask)))
         assert np.array_equal(host(pre_out), ref_out)
         assert np.array_equal(host(pre_share), ref_share)
+    pre_out, pre_share = server.conv2DSSPrepared(got_cts, None, prep, meta, (dev(u), dev(e1), dev(mask)),
+                                                 share_tensor=dev(share1) if shared else None)
+    assert np.array_equal(host(pre_out), ref_out) and np.array_equal(host(pre_share), ref_share)
     # ... and the online half alone, the encryptions of zero under the re-sharing made ahead of the input from the same u
     zeros = server.prepareZeros(meta, dev(u))
     on_out, on_share = server.conv2DSSOnline(got_cts, dev(share1) if shared else None, prep, zeros, meta,
