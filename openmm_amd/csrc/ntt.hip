@@ -28,6 +28,226 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   ntt_fwd_unit<LOGN, FOLD, SRC>(blockIdx.x, data, mods, tables, limbs, mod_base, src, lds);
 }
 
+// ---------------------------------------------------------------- N = 8192 with 512 threads
+// The 256-thread kernels hold 32 coefficients per lane at N = 8192 and their 68 KiB image lets two workgroups share a
+// CU: two waves per SIMD, too few to cover the latency of the passes.  These hold 16 per lane in 512 threads (four
+// waves per SIMD with the same two workgroups): passes of 4 + 4 + 4 stages on registers with the image in LDS between
+// them, and the 13th stage, whose pairs are adjacent coefficients, folded into the 16-byte-per-lane store (forward) or
+// load (inverse).  In place, plain source / sink only; the other forms keep the 256-thread kernels.
+//   pass A  k*512 + t            (stride 512: stages 0-3, wave-uniform twiddles)
+//   pass B  jhi*512 + k*32 + jlo (jhi = t >> 5, jlo = t & 31: stages 4-7)
+//   pass C  jhi*32 + k*2 + jlo   (jhi = t >> 1, jlo = t & 1: stages 8-11)
+//   pass D  pairs (2P, 2P + 1), P = k*512 + t (stage 12)
+template <bool FOLD>
+__global__ __launch_bounds__(512, 4) void ntt_fwd512_kernel(u64 *__restrict__ data, const DevMod *__restrict__ mods,
+                                                            const ulonglong2 *__restrict__ tables, int limbs,
+                                                            int mod_base) {
+  constexpr int N = 8192;
+  extern __shared__ __align__(16) u64 lds[];
+  const int t = threadIdx.x;
+  const DevMod &M = mods[mod_base + blockIdx.x % limbs];
+  const ulonglong2 *__restrict__ tw = tables + M.tw_offset;
+  u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
+  ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(a);
+  if (M.f64) {  // uniform over the workgroup
+    double *ldsd = reinterpret_cast<double *>(lds);
+    const F64Mod m{M.qd, M.qinv};
+    const double *__restrict__ twd = reinterpret_cast<const double *>(tw);
+    double wB[15], wC[15];
+    {
+      const double bias = 0x1p52 + 2.0 * m.q;  // inputs in [0, 4q) become |v| <= 2q
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = f64_from_u64(a[k * 512 + t], bias);
+      double wA[15];
+      load_twiddles_f64<4, 0>(tw, 0, wA);
+      load_twiddles_f64<4, 4>(tw, t >> 5, wB);
+      fwd_radix_f64<4, false>(x, wA, m);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ldsd[pad(k * 512 + t)] = x[k];
+    }
+    __syncthreads();
+    {
+      const int base = (t >> 5) * 512 + (t & 31);
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ldsd[pad(base + k * 32)];
+      load_twiddles_f64<4, 8>(tw, t >> 1, wC);
+      fwd_radix_f64<4, true>(x, wB, m);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ldsd[pad(base + k * 32)] = x[k];
+    }
+    __syncthreads();
+    {
+      const int base = (t >> 1) * 32 + (t & 1);
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ldsd[pad(base + k * 2)];
+      fwd_radix_f64<4, true>(x, wC, m);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ldsd[pad(base + k * 2)] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int P = k * 512 + t, j = pad(2 * P);
+      const double X = f64_reduce(ldsd[j], m), T = f64_mulmod(twd[4096 + P], ldsd[j + 1], m);
+      out[P] = make_ulonglong2(f64_canonical(X + T, m), f64_canonical(X - T, m));
+    }
+    return;
+  }
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
+  ulonglong2 wB[15], wC[15];
+  {
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = a[k * 512 + t];
+    ulonglong2 wA[15];
+    load_twiddles<4, 0>(tw, 0, wA);          // wave-uniform: scalar loads
+    load_twiddles<4, 4>(tw, t >> 5, wB);     // for pass B, in flight during pass A
+    fwd_radix<4, 0, FOLD, true>(x, wA, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(k * 512 + t)] = x[k];
+  }
+  __syncthreads();
+  {
+    const int base = (t >> 5) * 512 + (t & 31);
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(base + k * 32)];
+    load_twiddles<4, 8>(tw, t >> 1, wC);     // for pass C
+    fwd_radix<4, 4, FOLD>(x, wB, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(base + k * 32)] = x[k];
+  }
+  __syncthreads();
+  {
+    const int base = (t >> 1) * 32 + (t & 1);
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(base + k * 2)];
+    fwd_radix<4, 8, FOLD>(x, wC, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(base + k * 2)] = x[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int P = k * 512 + t, j = pad(2 * P);
+    const ulonglong2 w = tw[4096 + P];
+    const u64 X = rd.fwd_x(lds[j], 12);
+    const u64 A = shoup_mad(X, lds[j + 1], w.x, w.y, nq);
+    out[P] = make_ulonglong2(rd.fwd_final(A), rd.fwd_final(2 * X + rd.q4 - A));
+  }
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(512, 4) void ntt_inv512_kernel(u64 *__restrict__ data, const DevMod *__restrict__ mods,
+                                                            const ulonglong2 *__restrict__ tables, int limbs,
+                                                            int mod_base) {
+  constexpr int N = 8192;
+  extern __shared__ __align__(16) u64 lds[];
+  const int t = threadIdx.x;
+  const DevMod &M = mods[mod_base + blockIdx.x % limbs];
+  const ulonglong2 *__restrict__ tw = tables + M.tw_offset + N;
+  u64 *__restrict__ a = data + (size_t)blockIdx.x * N;
+  const ulonglong2 *__restrict__ in = reinterpret_cast<const ulonglong2 *>(a);
+  if (M.f64) {
+    double *ldsd = reinterpret_cast<double *>(lds);
+    const F64Mod m{M.qd, M.qinv};
+    const double *__restrict__ twd = reinterpret_cast<const double *>(tw);
+    const double bias = 0x1p52 + m.q;  // inputs in [0, 2q) become |v| <= q
+    double wC[15], wB[15];
+    load_twiddles_f64<4, 8>(tw, t >> 1, wC);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // stage 12 first (e = 0: sums are not reduced)
+      const int P = k * 512 + t, j = pad(2 * P);
+      const ulonglong2 v = in[P];
+      const double X = f64_from_u64(v.x, bias), Y = f64_from_u64(v.y, bias);
+      ldsd[j] = X + Y;
+      ldsd[j + 1] = f64_mulmod(twd[4096 + P], X - Y, m);
+    }
+    __syncthreads();
+    {
+      const int base = (t >> 1) * 32 + (t & 1);
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ldsd[pad(base + k * 2)];
+      load_twiddles_f64<4, 4>(tw, t >> 5, wB);
+      inv_radix_f64<4, 1>(x, wC, m);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ldsd[pad(base + k * 2)] = x[k];
+    }
+    __syncthreads();
+    {
+      const int base = (t >> 5) * 512 + (t & 31);
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ldsd[pad(base + k * 32)];
+      inv_radix_f64<4, 5>(x, wB, m);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ldsd[pad(base + k * 32)] = x[k];
+    }
+    __syncthreads();
+    {
+      double x[16], wA[15];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ldsd[pad(k * 512 + t)];
+      load_twiddles_f64<4, 0>(tw, 0, wA);
+      inv_radix_f64<4, 9>(x, wA, m);
+      const double ninv = (double)M.ninv;  // exact: below q < 2^49
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k * 512 + t] = f64_canonical(f64_mulmod(ninv, x[k], m), m);
+    }
+    return;
+  }
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
+  ulonglong2 wC[15], wB[15];
+  load_twiddles<4, 8>(tw, t >> 1, wC);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {   // stage 12 first (e = 0)
+    const int P = k * 512 + t, j = pad(2 * P);
+    const ulonglong2 v = in[P], w = tw[4096 + P];
+    lds[j] = rd.inv_sum(v.x + v.y, 0);
+    lds[j + 1] = shoup_mad(0, v.x + rd.inv_bias(0) - v.y, w.x, w.y, nq);
+  }
+  __syncthreads();
+  {
+    const int base = (t >> 1) * 32 + (t & 1);
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(base + k * 2)];
+    load_twiddles<4, 4>(tw, t >> 5, wB);
+    inv_radix<4, 8, 1, FOLD>(x, wC, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(base + k * 2)] = x[k];
+  }
+  __syncthreads();
+  {
+    const int base = (t >> 5) * 512 + (t & 31);
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(base + k * 32)];
+    inv_radix<4, 4, 5, FOLD>(x, wB, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(base + k * 32)] = x[k];
+  }
+  __syncthreads();
+  {
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(k * 512 + t)];
+    ulonglong2 wA[15];
+    load_twiddles<4, 0>(tw, 0, wA);
+    inv_radix<4, 0, 9, FOLD, true>(x, wA, nq, rd);
+    const u64 ninv = M.ninv, ninv_sh = M.ninv_sh;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k * 512 + t] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
+  }
+}
+
 // What becomes of the coefficients an inverse transform produces.
 //   SINK_STORE    written in place.
 //   SINK_RESHARE  unit (p, j) is component j of the pk-encryption of zero of output ciphertext p at the last level
@@ -400,6 +620,29 @@ static int dispatch(const mmh_ctx *ctx, int mode, u64 *d, const NttSource &src, 
   MMH_REQUIRE(blocks <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
   bool fold = true;  // every modulus of this launch must have the 2^b - c shape for the fast reducer
   for (int l = 0; l < limbs; ++l) fold = fold && ctx->h_mods[mod_base + l].fold_c != 0;
+  // N = 8192 in place: the 512-thread kernels where they measure faster -- the inverse transform (445 against 470 us
+  // per 2048 x {60,60,60,49}) and forward launches whose moduli all take the double-precision butterflies (126-130
+  // against 132-138 us per 4096).  The forward integer butterflies are bound by the vector ALU at either occupancy
+  // (1.08 T butterflies/s at N = 8192 as at N = 4096) and lose 12 % to the extra LDS pass.  MMH_NTT_512=0 / 1 forces
+  // the 256- / 512-thread kernels (A/B measurements, tests of both).
+  bool all_f64 = true;
+  for (int l = 0; l < limbs; ++l) all_f64 = all_f64 && ctx->h_mods[mod_base + l].f64;
+  if (ctx->logN == 13 && (mode == SRC_INPLACE || mode == -1)) {
+    const char *e = getenv("MMH_NTT_512");
+    const bool use512 = e ? e[0] != '0' : (mode == -1 || all_f64);
+    if (use512) {
+      auto go = [&](auto kern) -> int {
+        MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes<13>()));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes<13>(), s, d, ctx->d_mods, ctx->d_tables,
+                           limbs, mod_base);
+        MMH_HIP(hipGetLastError());
+        return MMH_OK;
+      };
+      if (mode == -1) return fold ? go(ntt_inv512_kernel<true>) : go(ntt_inv512_kernel<false>);
+      return fold ? go(ntt_fwd512_kernel<true>) : go(ntt_fwd512_kernel<false>);
+    }
+  }
   switch (ctx->logN) {
     case 12: return launch<12>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s, fin);
     case 13: return launch<13>(mode, fold, d, ctx, blocks, limbs, mod_base, src, s, fin);

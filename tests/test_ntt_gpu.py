@@ -42,6 +42,35 @@ def test_forward_inverse_bit_exact(mm, N, bits, n_polys):
     assert np.array_equal(to_host(d), a)
 
 
+@pytest.mark.parametrize("threads512", ["0", "1"])
+@pytest.mark.parametrize("f64", ["0", "1"])
+def test_n8192_both_kernel_families(mm, monkeypatch, threads512, f64):
+    """N = 8192 has 256-thread kernels (32 coefficients per lane) and 512-thread kernels (16 per lane, the last stage
+    folded into the store / load); the dispatcher picks per launch (ntt.hip).  Both, forced, forward and inverse, on the
+    integer and on the double-precision butterflies, against the oracle: random, all-(q-1) and half-zero polynomials."""
+    from openmm_amd.lib import to_device, to_host
+    monkeypatch.setenv("MMH_NTT_512", threads512)     # read on every launch
+    monkeypatch.setenv("MMH_NTT_F64", f64)            # read when the context is made
+    N, bits = 8192, (60, 60, 60, 49)
+    o, g = OracleCtx(N, bits, 0), mm.Context(N, bits, 0)
+    a = _polys(o, 5, SEED + 512)
+    a[1] = np.array(o.q, dtype=np.uint64)[:, None] - np.uint64(1)
+    a[2, :, ::2] = 0
+    d = to_device(a)
+    g.ntt_forward(d)
+    assert np.array_equal(to_host(d), o.ntt_forward(a))
+    g.ntt_inverse(d)
+    assert np.array_equal(to_host(d), a)
+    # single-limb launches on the 49-bit prime (the case the dispatcher sends to the 512-thread forward kernel)
+    g1 = mm.Context(N, q=[o.q[3]])
+    b = np.ascontiguousarray(a[:, 3:4])
+    d = to_device(b)
+    g1.ntt_forward(d)
+    assert np.array_equal(to_host(d), o.ntt_forward(a)[:, 3:4])
+    g1.ntt_inverse(d)
+    assert np.array_equal(to_host(d), b)
+
+
 def test_edge_values_and_single_limb(mm):
     """all-zero, all q-1, a single monomial; limbs=1 uses q[0] only; empty batch is a no-op"""
     from openmm_amd.lib import to_device, to_host
