@@ -626,17 +626,66 @@ __device__ __forceinline__ void fold_words(u32 &w0, u32 &w1, u32 &w2, u32 w3, u3
 // Workgroups are dealt to the XCDs round robin by the dispatcher; the index arithmetic below gives each XCD
 // whole column tiles, all of whose filter tiles then stream the same digits (measured within 3 % of the plain
 // order: the digit image sits in the Infinity Cache either way).
+// The rare form inside the product kernel: some weight of the layer is 2^20 or more in magnitude, so the byte-digit
+// product does not apply and the workgroup computes its 128 filters x 64 columns on the vector ALU from the lifted
+// 64-bit weights, exactly as pw_gemm_kernel<false> does (lazy 128-bit sums reduced every 8 taps, canonical results).
+// A branch here instead of a second launch that nearly always exits at once (4-5 us per layer).  Not tuned: wave w
+// takes filters 16 w .. 16 w + 15, every lane one column, the rotated column value re-read per tap.
+__device__ __noinline__ void pw_general_tile(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+                                             const u64 *__restrict__ wl, u64 *__restrict__ acc, int M, int Mpad,
+                                             int Cpad, size_t S, int logN, const DevMod *__restrict__ mods, size_t c0,
+                                             int mt) {
+  const int N = 1 << logN, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t cols = S * 4 * N, col = c0 + lane;
+  const int i = (int)(col & (N - 1)), pl = (int)((c0 >> logN) & 3), l = pl & 1;
+  const size_t sp = c0 >> (logN + 2);
+  const int mbase = mt * 128 + wave * 16;
+  if (mbase >= M) return;
+  const DevMod q = mods[l];
+  const u64 *__restrict__ base = image + ((sp * 4 + pl) << logN);
+  const size_t row_step = S * 4 * N;
+  const u64 *__restrict__ wg = wl + (size_t)l * Cpad * Mpad + mbase;
+  const int nf = min(16, Mpad - mbase);
+  u64 x0[16], x1[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) x0[j] = x1[j] = 0;
+  for (int k = 0; k < Cpad; ++k) {
+    const PwChannel pc = chan[k];
+    const u64 v = base[(size_t)pc.row * row_step + ((i - pc.e) & (N - 1))];
+    const u64 u = i < pc.e ? (v ? q.q - v : 0) : v;   // X^N = -1
+    const u64 *__restrict__ wr = wg + (size_t)k * Mpad;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const u64 wj = j < nf ? wr[j] : 0, p = u * wj;
+      x0[j] += p;
+      x1[j] += mulhi64(u, wj) + (x0[j] < p);
+    }
+    if ((k & 7) == 7) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x0[j] = reduce128_wide(x1[j], x0[j], q), x1[j] = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (mbase + j < M) acc[(size_t)(mbase + j) * cols + col] = x0[j];
+}
+
 constexpr int kPwLdsBytes = 3 * (2048 + 1024) * 16;   // 144 KiB: three buffers of 2 weight digits (two of 3 fit too)
 __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ u8, const uint4 *__restrict__ w8,
                                                       const u32 *__restrict__ flag, const int *__restrict__ live,
                                                       u64 *__restrict__ acc, int M, int MT, int KC, int n_live,
-                                                      size_t S, int logN, const DevMod *__restrict__ mods) {
+                                                      size_t S, int logN, const DevMod *__restrict__ mods,
+                                                      const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+                                                      const u64 *__restrict__ wl, int Mpad, int Cpad) {
   extern __shared__ uint4 pw_lds[];
   const int seq = blockIdx.x >> 3, slot = (seq / MT) * 8 + (blockIdx.x & 7), mt = seq % MT;
   if (slot >= n_live) return;
   const u32 fl = *flag;                 // both loads in flight together: a workgroup has the CU to itself, so every
   const int tile = live[slot];          // dependent load at its start is exposed latency
-  if (fl & 1u) return;
+  if (fl & 1u) {                        // weights of 2^20 and more: the lifted form (rare)
+    pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)tile * 64, mt);
+    return;
+  }
   const int nA = (fl & 2u) ? 3 : 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
@@ -842,15 +891,17 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
-                       ctx->logN, ctx->d_mods);
+                       ctx->logN, ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad);
     (void)scratch_free(u8, s);
   }
+  // (on the matrix-core path the product kernel carries the lifted-weight form as a branch of its own)
+  const bool fallback_launch = form != 0 && (!mfma || form == 1);
   if (wide) {
     if (!mfma && form != 1) launch(pw_gemm_kernel<true, 16>, 64);
-    if (form != 0) launch(pw_gemm_kernel<false, 16>, 64);
+    if (fallback_launch) launch(pw_gemm_kernel<false, 16>, 64);
   } else {
     if (!mfma && form != 1) launch(pw_gemm_kernel<true, 8>, 32);
-    if (form != 0) launch(pw_gemm_kernel<false, 8>, 32);
+    if (fallback_launch) launch(pw_gemm_kernel<false, 8>, 32);
   }
   MMH_HIP(hipGetLastError());
   return MMH_OK;
