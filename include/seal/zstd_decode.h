@@ -387,6 +387,8 @@ inline void decode_block(FrameState &st, const std::uint8_t *src, std::size_t n,
     }
   }
   std::size_t lit_pos = 0;
+  const std::size_t block_start = out.size();
+  constexpr std::size_t kBlockMax = (std::size_t)128 * 1024;   // Block_Maximum_Size: what a block may regenerate
   if (nseq) {
     in.need(1);
     const int modes = *in.p++;
@@ -428,6 +430,7 @@ inline void decode_block(FrameState &st, const std::uint8_t *src, std::size_t n,
       out.insert(out.end(), lit.begin() + (long)lit_pos, lit.begin() + (long)(lit_pos + ll));
       lit_pos += ll;
       if (off > out.size() - frame_start) throw Error("match offset before the start of the frame");
+      if (out.size() - block_start + ml > kBlockMax) throw Error("block expands past the maximum block size");
       const std::size_t from = out.size() - (std::size_t)off;
       for (std::size_t k = 0; k < ml; ++k) {   // byte by byte: overlapping copies repeat the pattern
         const std::uint8_t v = out[from + k];
