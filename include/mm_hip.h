@@ -515,6 +515,20 @@ int mmh_f2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const u
                  uint64_t p, int bw, uint64_t *d_out, void *stream);
 int mmh_f2r_trunc_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y, size_t n,
                        uint64_t p, int bw, int shift, uint64_t *d_out, void *stream);
+/* Conversions fused with the HomBNSS vector step next to them.  CheetahLinear::bn / ::BOLE
+ * convert their shares with ring_to_field, hand the field elements to encodeVector / encryptVector, and convert
+ * decryptToVector's output back with field_to_ring[_with_truncate] (cheetah-api.cpp:560-660,
+ * library_fixed_uniform_cheetah.cpp:492-565).  With everything resident the element need not travel through memory
+ * between the two: _r2f = mmh_r2f_post (p = the context's field modulus t) + mmh_bn_encode_vector / _encrypt_vector,
+ * _f2r = mmh_bn_decrypt_vector + mmh_f2r_pre (shift = 0 for the plain variant); same bits as the calls they replace,
+ * 25 instead of 57 bytes of traffic per element on the encode side. */
+int mmh_bn_encode_vector_r2f(const mmh_ctx *ctx, int party, const uint64_t *d_tmp, const uint8_t *d_msb,
+                             const uint64_t *d_y, size_t n, int bw, uint64_t *d_pts, void *stream);
+int mmh_bn_encrypt_vector_r2f(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, int party, const uint64_t *d_tmp,
+                              const uint8_t *d_msb, const uint64_t *d_y, size_t n, int bw, const uint64_t *d_a,
+                              const int64_t *d_e, uint64_t *d_cts, void *stream);
+int mmh_bn_decrypt_vector_f2r(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n, int party,
+                              int shift, uint64_t *d_tmp, uint8_t *d_msb, uint64_t *d_corr, void *stream);
 /* Truncation::ring_to_ring (:319-381) and ring_to_ring128 (:383-442; d_out holds (lo,hi) pairs) */
 int mmh_r2r_pre(int party, const uint64_t *d_in, size_t n, int bw_a, uint64_t *d_tmp, uint8_t *d_msb,
                 uint64_t *d_corr, void *stream);

@@ -5,16 +5,9 @@
 // ~25 B per element); the COT between them is the caller's (host, or cot.hip's device post-processing).
 // party: 1 = ALICE (COT sender), 2 = BOB.
 #include "common.hpp"
+#include "convert_device.hpp"
 
 namespace mmh {
-constexpr int kAlice = 1;
-
-__device__ __forceinline__ u64 bw_mask(int bw) { return bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1; }
-// truncation.cpp:533-541.  x may exceed p (it is an l-bit ring value): keep the reference's
-// non-canonical results bit for bit.
-__device__ __forceinline__ u64 secure_add(u64 x, u64 y, u64 p) { return x >= (p - y) ? x - (p - y) : x + y; }
-__device__ __forceinline__ u64 secure_sub(u64 x, u64 y, u64 p) { return x >= y ? x - y : x + (p - y); }
-
 // mode 0: ring (+2^{bw-2}, msb = bit bw-1); mode 1: field (+p/4 mod p, msb = tmp >= p/2+1)
 template <int MODE>
 __global__ __launch_bounds__(256) void pre_kernel(int party, const u64 *__restrict__ in, size_t n, int bw, u64 p,
@@ -28,9 +21,7 @@ __global__ __launch_bounds__(256) void pre_kernel(int party, const u64 *__restri
     if (party == kAlice) v = (v + (u64(1) << (bw - 2))) & bw_mask(bw);
     m = (v >> (bw - 1)) & 1;
   } else {
-    const u64 big = p / 4;
-    if (party == kAlice) v = v >= p - big ? v - p + big : v + big;
-    m = v >= p / 2 + 1;
+    v = f2r_pre_elem(party, v, p, m);
   }
   tmp[i] = v;
   msb[i] = m;
@@ -43,14 +34,7 @@ __global__ __launch_bounds__(256) void r2f_post_kernel(int party, const u64 *__r
                                                        u64 *__restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  u64 yy = y[i];
-  if (party == kAlice) {  // truncation.cpp:551-554
-    const u64 t = secure_sub(0, yy, p);
-    yy = msb[i] ? secure_add(cv, t, p) : t;
-  }
-  u64 o = secure_sub(tmp[i], yy, p);  // :571 / :576
-  if (party == kAlice) o = secure_sub(o, big_mod_p, p);
-  out[i] = o;
+  out[i] = r2f_post_elem(party, tmp[i], msb[i], y[i], p, cv, big_mod_p);
 }
 
 // truncating = 0: truncation.cpp:609-611,:626-634; truncating = 1: :667-669,:684-692

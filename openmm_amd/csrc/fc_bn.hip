@@ -3,6 +3,7 @@
 // decryptToVector) as layer-level calls built from the batched kernels.
 #include "bfv_device.hpp"
 #include "common.hpp"
+#include "convert_device.hpp"
 #include "geometry.hpp"
 
 namespace mmh {
@@ -86,6 +87,38 @@ __global__ __launch_bounds__(256) void chunk_unpad_kernel(const u64 *__restrict_
   const size_t src = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (src >= n) return;
   vec[src] = slots[((src / sub_len) << logN) + src % sub_len];
+}
+// A conversion step inside the neighbouring HomBNSS step (CheetahLinear::bn / ::BOLE convert their shares with
+// ring_to_field, hand the field elements to encodeVector / encryptVector, and take decryptToVector's output to
+// field_to_ring, cheetah-api.cpp:560-660): the element never makes the round trip through memory between the two.
+// ring_to_field's post step -> chunking -> BatchEncoder's slot order (the inverse transform follows):
+__global__ __launch_bounds__(256) void r2f_post_scatter_kernel(int party, const u64 *__restrict__ tmp,
+                                                               const uint8_t *__restrict__ msb,
+                                                               const u64 *__restrict__ y, u64 *__restrict__ pts,
+                                                               size_t n_ct, size_t n, size_t sub_len, int logN,
+                                                               const u32 *__restrict__ map, ModC t, u64 cv,
+                                                               u64 big_mod_p) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_ct << logN)) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const size_t src = k * sub_len + i;
+  u64 v = 0;
+  if (i < sub_len && src < n) v = r2f_post_elem(party, tmp[src], msb[src], y[src], t.q, cv, big_mod_p);
+  pts[(k << logN) + map[i]] = barrett128(0, v, t.q, t.barrett_hi, t.barrett_lo);   // BatchEncoder reduces mod t
+}
+// BatchEncoder's slot order after the forward transform -> un-chunking -> field_to_ring's pre step:
+__global__ __launch_bounds__(256) void gather_f2r_pre_kernel(int party, const u64 *__restrict__ slots_ntt,
+                                                             size_t n, size_t sub_len, int logN,
+                                                             const u32 *__restrict__ map, u64 p, u64 corr_value,
+                                                             u64 *__restrict__ tmp, uint8_t *__restrict__ msb,
+                                                             u64 *__restrict__ corr) {
+  const size_t src = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (src >= n) return;
+  bool m;
+  const u64 v = f2r_pre_elem(party, slots_ntt[((src / sub_len) << logN) + map[src % sub_len]], p, m);
+  tmp[src] = v;
+  msb[src] = m;
+  if (party == kAlice && corr) corr[src] = m ? 0 : corr_value;
 }
 // addMask (hom_bn_ss.cc:333-340): r = random % p in place, share = -r mod p
 __global__ __launch_bounds__(256) void bn_mask_kernel(const u64 *__restrict__ random, u64 *__restrict__ r,
@@ -438,6 +471,62 @@ extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
   }
   (void)scratch_free(pts, s);
   if (slots) (void)scratch_free(slots, s);
+  return rc;
+}
+
+// ---- conversions fused with the neighbouring vector step (same bits as the two calls they replace)
+namespace mmh {
+int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs, int mod_base, hipStream_t s);
+}
+extern "C" int mmh_bn_encode_vector_r2f(const mmh_ctx *ctx, int party, const uint64_t *d_tmp, const uint8_t *d_msb,
+                                        const uint64_t *d_y, size_t n, int bw, uint64_t *d_pts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_tmp && d_msb && d_y && d_pts, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE((party == 1 || party == 2) && bw >= 2 && bw <= 64, MMH_ERR_INVALID_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  const u64 p = ctx->t, mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
+  hipLaunchKernelGGL(r2f_post_scatter_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, party, d_tmp, d_msb, d_y,
+                     d_pts, n_ct, n, sub, ctx->logN, ctx->d_slot_map, ctx->bfv.t, mask % p + 1, (u64(1) << (bw - 2)) % p);
+  MMH_HIP(hipGetLastError());
+  return ntt_dispatch(ctx, true, d_pts, n_ct, 1, (int)ctx->L, s);   // BatchEncoder::encode's inverse transform mod t
+}
+extern "C" int mmh_bn_encrypt_vector_r2f(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, int party, const uint64_t *d_tmp,
+                                         const uint8_t *d_msb, const uint64_t *d_y, size_t n, int bw,
+                                         const uint64_t *d_a, const int64_t *d_e, uint64_t *d_cts, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_sk_ntt && d_a && d_e && d_cts, MMH_ERR_NULL_POINTER);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(scratch_alloc(&pts, (n_ct << ctx->logN) * 8, s));
+  int rc = mmh_bn_encode_vector_r2f(ctx, party, d_tmp, d_msb, d_y, n, bw, (u64 *)pts, stream);
+  if (!rc) rc = mmh_encrypt_symmetric(ctx, 0, d_sk_ntt, d_a, d_e, (const u64 *)pts, n_ct, d_cts, stream);
+  (void)scratch_free(pts, s);
+  return rc;
+}
+extern "C" int mmh_bn_decrypt_vector_f2r(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_cts, size_t n,
+                                         int party, int shift, uint64_t *d_tmp, uint8_t *d_msb, uint64_t *d_corr,
+                                         void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_sk_ntt && d_cts && d_tmp && d_msb, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE((party == 1 || party == 2) && shift >= 0 && shift < 64, MMH_ERR_INVALID_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  void *pts = nullptr;
+  MMH_HIP(scratch_alloc(&pts, (n_ct << ctx->logN) * 8, s));
+  int rc = mmh_decrypt(ctx, 1, d_sk_ntt, d_cts, n_ct, (u64 *)pts, stream);  // hom_bn_ss.cc:389
+  // BatchEncoder::decode's forward transform mod t in place, then the gather in slot order straight into the pre step
+  if (!rc) rc = ntt_dispatch(ctx, false, (u64 *)pts, n_ct, 1, (int)ctx->L, s);
+  if (!rc) {
+    hipLaunchKernelGGL(gather_f2r_pre_kernel, dim3(nblk(n)), dim3(256), 0, s, party, (const u64 *)pts, n, sub, ctx->logN,
+                       ctx->d_slot_map, ctx->t, ctx->t >> shift, d_tmp, d_msb, d_corr);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
+  (void)scratch_free(pts, s);
   return rc;
 }
 

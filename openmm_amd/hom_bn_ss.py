@@ -134,6 +134,46 @@ class HomBNSS:
 
     encodeScales = encodeVector  # :235-239
 
+    # Conversions fused with the vector step next to them (include/mm_hip.h: mmh_bn_*_r2f / _f2r).  `conv` is what
+    # ring_to_field holds after its COT -- (tmp [n], msb [n] uint8, y [n]) -- and ring_bw its bit width; the field
+    # modulus is the context's t.  Same bits as ring_to_field's post step followed by encodeVector / encryptVector.
+    def encodeVectorFromRing(self, party, conv, ring_bw, meta):
+        self._check(meta)
+        n, n_ct = self._n_ct(meta)
+        tmp, msb, y = conv
+        self._need(tmp.numel() == n and msb.numel() == n and y.numel() == n, 3, "encodeVector: conversion buffers")
+        out = self.ctx._empty(n_ct, self.ctx.N)
+        L.check(self.ctx.lib.mmh_bn_encode_vector_r2f(self.ctx.handle, party, L.dptr(tmp), L.dptr(msb), L.dptr(y), n,
+                                                      ring_bw, L.dptr(out), L._stream_ptr()))
+        return out
+
+    def encryptVectorFromRing(self, party, conv, ring_bw, meta, rand):
+        self._check(meta)
+        self._need(self.sk_ntt is not None, 1, "encryptVector: no secret key")
+        n, n_ct = self._n_ct(meta)
+        tmp, msb, y = conv
+        self._need(tmp.numel() == n and msb.numel() == n and y.numel() == n, 3, "encryptVector: conversion buffers")
+        a, e = rand
+        out = self.ctx._empty(n_ct, 2, self.ctx.L, self.ctx.N)
+        L.check(self.ctx.lib.mmh_bn_encrypt_vector_r2f(self.ctx.handle, L.dptr(self.sk_ntt), party, L.dptr(tmp),
+                                                       L.dptr(msb), L.dptr(y), n, ring_bw, L.dptr(a), L.dptr(e),
+                                                       L.dptr(out), L._stream_ptr()))
+        return out
+
+    def decryptToVectorForRing(self, in_vec, meta, party, shift=0):
+        """decryptToVector feeding field_to_ring's pre step (shift > 0: field_to_ring_with_truncate's): returns
+        (tmp [n], msb [n] uint8, corr [n]) as mmh_f2r_pre would from the decrypted vector"""
+        import torch
+        self._check(meta)
+        self._need(self.sk_ntt is not None, 1, "decryptToVector: no secret key")
+        n, n_ct = self._n_ct(meta)
+        self._need(in_vec.shape[0] == n_ct, 7, "decryptToVector: #ciphertexts")
+        tmp, corr = self.ctx._empty(n), self.ctx._empty(n)
+        msb = torch.empty(n, dtype=torch.uint8, device=tmp.device)
+        L.check(self.ctx.lib.mmh_bn_decrypt_vector_f2r(self.ctx.handle, L.dptr(self.sk_last), L.dptr(in_vec), n, party,
+                                                       shift, L.dptr(tmp), L.dptr(msb), L.dptr(corr), L._stream_ptr()))
+        return tmp, msb, corr
+
     def bn(self, vec_share0, vec_share1, scales, meta, random):  # :241-278
         self._check(meta)
         n, n_ct = self._n_ct(meta)

@@ -108,6 +108,9 @@ SIGNATURES = {
     "mmh_conv_filters_destroy": [_vp],
     "mmh_conv_server_prepared": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server_prepared_tensors": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_bn_encode_vector_r2f": [_vp, C.c_int, _vp, _vp, _vp, _sz, C.c_int, _vp, _vp],
+    "mmh_bn_encrypt_vector_r2f": [_vp, _vp, C.c_int, _vp, _vp, _vp, _sz, C.c_int, _vp, _vp, _vp, _vp],
+    "mmh_bn_decrypt_vector_f2r": [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
     "mmh_reshare_zero_prepare": [_vp, _vp, _vp, _sz, _vp, _vp],
     "mmh_conv_server_online": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_decrypt": [_vp, _vp, _vp, _vp, _vp],

@@ -155,6 +155,49 @@ def test_bole_bn_bit_exact(mm, n):
     assert np.array_equal(host(got_out), ref_out) and np.array_equal(host(got_share), ref_share)
 
 
+@pytest.mark.parametrize("n", [1, 100, 4096, 10000, 70001])
+@pytest.mark.parametrize("party", [1, 2])
+def test_bn_vector_steps_fused_with_conversions(mm, n, party):
+    """ring_to_field's post step straight into encodeVector / encryptVector, and decryptToVector straight into
+    field_to_ring's pre step (cheetah-api.cpp:493-561 runs them back to back): the fused entry points against the
+    oracle's two steps, bit for bit"""
+    from openmm_amd.hom_bn_ss import HomBNSS, Meta
+    from tests.oracle_binding import A, load
+    ol = load()
+    o, g = OracleCtx(N, (60, 49), P32), mm.Context(N, (60, 49), P32)
+    bn = BnOracle(o, n)
+    meta = Meta((n,), P32, True)
+    sk, _ = keypair(o)
+    h = HomBNSS()
+    h.setUp_Field(P32, g, sk_ntt=dev(sk))
+    bw = 37
+    x = splitmix64(SEED + 30, n) & np.uint64((1 << bw) - 1)
+    x[:min(3, n)] = [0, (1 << bw) - 1, 1 << (bw - 1)][:min(3, n)]
+    y = splitmix64(SEED + 31, n) & np.uint64((1 << bw) - 1)
+    tmp, msb, corr, fld = (np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint64),
+                           np.zeros(n, np.uint64))
+    ol.mmo_r2f_pre(party, A(x), n, bw, P32, A(tmp), A(msb), A(corr))
+    ol.mmo_r2f_post(party, A(tmp), A(msb), A(y), n, bw, P32, A(fld))
+    conv = (dev(tmp), dev(msb), dev(y))
+    assert np.array_equal(host(h.encodeVectorFromRing(party, conv, bw, meta)), bn.encode(fld))
+    a, e = rns_uniform(o, SEED + 32, bn.n_ct, 2), noise(SEED + 33, (bn.n_ct, N))
+    cts = h.encryptVectorFromRing(party, conv, bw, meta, (dev(a), dev(e)))
+    ref_cts = bn.encrypt(sk, fld, a, e)
+    assert np.array_equal(host(cts), ref_cts)
+    # the way back: decrypt one-limb results (flood and drop the special prime as bn does) into the pre step
+    scale, rnd = bn.encode(uniform_mod(SEED + 34, n, P32)), splitmix64(SEED + 35, n)
+    out_ct, _ = bn.bn(ref_cts, bn.encode(np.zeros(n, np.uint64)), scale, rnd)
+    dec = bn.decrypt(np.ascontiguousarray(sk[:1]), out_ct)
+    for shift in (0, 12):
+        ol.mmo_f2r_pre(party, A(dec), n, P32, shift, A(tmp), A(msb), A(corr))
+        g_tmp, g_msb, g_corr = h.decryptToVectorForRing(dev(out_ct), meta, party, shift)
+        assert np.array_equal(host(g_tmp), tmp) and np.array_equal(g_msb.cpu().numpy(), msb)
+        if party == 1:
+            assert np.array_equal(host(g_corr), corr)
+    with pytest.raises(mm.MMHError):
+        h.decryptToVectorForRing(dev(out_ct), meta, 3)
+
+
 def test_bole_full_size_identity(mm):
     """bole_test flags 1 1 size: 2^20 elements, l=32, |x|,|y| < 2^12 (tests/bole_test.cpp:78,98,568)"""
     import torch
