@@ -8,49 +8,107 @@
 #include "convert_device.hpp"
 
 namespace mmh {
+// The streaming kernels below take V = 2 elements per lane (16-byte loads and stores, 2 for the bit arrays) when every
+// array they touch is 16-byte aligned, V = 1 otherwise (aligned_pairs below); the last lane of an odd n does one.
+template <int V>
+__device__ __forceinline__ void load_elems(const u64 *__restrict__ p, size_t i, bool pair, u64 (&r)[2]) {
+  if (V == 2 && pair) {
+    const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(p + i);
+    r[0] = t.x, r[1] = t.y;
+  } else {
+    r[0] = p[i], r[1] = 0;
+  }
+}
+template <int V>
+__device__ __forceinline__ void store_elems(u64 *__restrict__ p, size_t i, bool pair, const u64 (&r)[2]) {
+  if (V == 2 && pair) *reinterpret_cast<ulonglong2 *>(p + i) = make_ulonglong2(r[0], r[1]);
+  else p[i] = r[0];
+}
+template <int V>
+__device__ __forceinline__ void load_bits(const uint8_t *__restrict__ p, size_t i, bool pair, uint8_t (&r)[2]) {
+  if (V == 2 && pair) {
+    const uchar2 t = *reinterpret_cast<const uchar2 *>(p + i);
+    r[0] = t.x, r[1] = t.y;
+  } else {
+    r[0] = p[i], r[1] = 0;
+  }
+}
+template <int V>
+__device__ __forceinline__ void store_bits(uint8_t *__restrict__ p, size_t i, bool pair, const uint8_t (&r)[2]) {
+  if (V == 2 && pair) *reinterpret_cast<uchar2 *>(p + i) = make_uchar2(r[0], r[1]);
+  else p[i] = r[0];
+}
+
 // mode 0: ring (+2^{bw-2}, msb = bit bw-1); mode 1: field (+p/4 mod p, msb = tmp >= p/2+1)
-template <int MODE>
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void pre_kernel(int party, const u64 *__restrict__ in, size_t n, int bw, u64 p,
                                                   u64 corr_value, int corr_is_not_msb, u64 *__restrict__ tmp,
                                                   uint8_t *__restrict__ msb, u64 *__restrict__ corr) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= n) return;
-  u64 v = in[i];
-  bool m;
-  if (MODE == 0) {
-    if (party == kAlice) v = (v + (u64(1) << (bw - 2))) & bw_mask(bw);
-    m = (v >> (bw - 1)) & 1;
-  } else {
-    v = f2r_pre_elem(party, v, p, m);
+  const bool pair = i + 1 < n;
+  u64 v[2], c[2];
+  uint8_t mb[2];
+  load_elems<V>(in, i, pair, v);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    bool m;
+    if (MODE == 0) {
+      if (party == kAlice) v[e] = (v[e] + (u64(1) << (bw - 2))) & bw_mask(bw);
+      m = (v[e] >> (bw - 1)) & 1;
+    } else {
+      v[e] = f2r_pre_elem(party, v[e], p, m);
+    }
+    mb[e] = m;
+    c[e] = corr_is_not_msb ? (u64)(!m) : (m ? 0 : corr_value);
   }
-  tmp[i] = v;
-  msb[i] = m;
-  if (party == kAlice && corr) corr[i] = corr_is_not_msb ? (u64)(!m) : (m ? 0 : corr_value);
+  store_elems<V>(tmp, i, pair, v);
+  store_bits<V>(msb, i, pair, mb);
+  if (party == kAlice && corr) store_elems<V>(corr, i, pair, c);
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void r2f_post_kernel(int party, const u64 *__restrict__ tmp,
                                                        const uint8_t *__restrict__ msb, const u64 *__restrict__ y,
                                                        size_t n, u64 p, u64 cv, u64 big_mod_p,
                                                        u64 *__restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= n) return;
-  out[i] = r2f_post_elem(party, tmp[i], msb[i], y[i], p, cv, big_mod_p);
+  const bool pair = i + 1 < n;
+  u64 t[2], yy[2], o[2];
+  uint8_t mb[2];
+  load_elems<V>(tmp, i, pair, t);
+  load_elems<V>(y, i, pair, yy);
+  load_bits<V>(msb, i, pair, mb);
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[e] = r2f_post_elem(party, t[e], mb[e], yy[e], p, cv, big_mod_p);
+  store_elems<V>(out, i, pair, o);
 }
 
 // truncating = 0: truncation.cpp:609-611,:626-634; truncating = 1: :667-669,:684-692
+template <int V>
 __global__ __launch_bounds__(256) void f2r_post_kernel(int party, const u64 *__restrict__ tmp,
                                                        const uint8_t *__restrict__ msb, const u64 *__restrict__ y,
                                                        size_t n, u64 p, int bw, int shift, int truncating,
                                                        u64 *__restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= n) return;
+  const bool pair = i + 1 < n;
   const u64 mask = bw_mask(bw), big = p / 4, cv = truncating ? p >> shift : p;
-  u64 yy = y[i];
-  if (party == kAlice) yy = msb[i] ? ((cv - yy) & mask) : ((0 - yy) & mask);
-  u64 o;
-  if (!truncating) o = party == kAlice ? tmp[i] - yy - big : tmp[i] - yy;
-  else o = party == kAlice ? ((tmp[i] - big) >> shift) - yy : (tmp[i] >> shift) - yy + 1;
-  out[i] = o & mask;
+  u64 t[2], yv[2], o[2];
+  uint8_t mb[2];
+  load_elems<V>(tmp, i, pair, t);
+  load_elems<V>(y, i, pair, yv);
+  load_bits<V>(msb, i, pair, mb);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    u64 yy = yv[e];
+    if (party == kAlice) yy = mb[e] ? ((cv - yy) & mask) : ((0 - yy) & mask);
+    if (!truncating) o[e] = party == kAlice ? t[e] - yy - big : t[e] - yy;
+    else o[e] = party == kAlice ? ((t[e] - big) >> shift) - yy : (t[e] >> shift) - yy + 1;
+    o[e] &= mask;
+  }
+  store_elems<V>(out, i, pair, o);
 }
 
 // truncation.cpp:353-355,:371-379 (64-bit) and :414-416,:434-442 (128-bit, WIDE)
@@ -92,32 +150,45 @@ __global__ __launch_bounds__(256) void r2r_post_kernel(int party, const u64 *__r
 // Truncation::truncate / truncate_msb / truncate_msb0 of the USE_CHEETAH build (truncation-cheetah.cpp:2-218):
 // the share arithmetic before the wrap sub-protocol (heuristic offset on BOB :23-29, signed offset on ALICE
 // :42-47, operand of mill->compare :51-56) ...
+template <int V>
 __global__ __launch_bounds__(256) void trunc_pre_kernel(int party, const u64 *__restrict__ in, size_t n, int bw,
                                                         int signed_arith, int heuristic, u64 *__restrict__ adj,
                                                         u64 *__restrict__ cmp) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= n) return;
+  const bool pair = i + 1 < n;
   const u64 mask = bw_mask(bw);
-  u64 v = in[i];
-  if (heuristic && party != kAlice) v = (v + (u64(1) << (bw - 3))) & mask;
-  if (signed_arith && party == kAlice) v = (v + (u64(1) << (bw - 1))) & mask;
-  adj[i] = v;
-  if (cmp) {
-    const u64 c = v & mask;
-    cmp[i] = party == kAlice ? c : (mask - c) & mask;
+  u64 v[2], c[2];
+  load_elems<V>(in, i, pair, v);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    if (heuristic && party != kAlice) v[e] = (v[e] + (u64(1) << (bw - 3))) & mask;
+    if (signed_arith && party == kAlice) v[e] = (v[e] + (u64(1) << (bw - 1))) & mask;
+    const u64 w = v[e] & mask;
+    c[e] = party == kAlice ? w : (mask - w) & mask;
   }
+  store_elems<V>(adj, i, pair, v);
+  if (cmp) store_elems<V>(cmp, i, pair, c);
 }
 // ... and after B2A (:64-75 = :133-144 = :201-212; heuristic :32-34); aw = arithmetic share of the wrap bit
+template <int V>
 __global__ __launch_bounds__(256) void trunc_post_kernel(int party, const u64 *__restrict__ adj,
                                                          const u64 *__restrict__ aw, size_t n, int shift, int bw,
                                                          int signed_arith, int heuristic, u64 *__restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= n) return;
+  const bool pair = i + 1 < n;
   const u64 mask = bw_mask(bw);
-  u64 o = (((adj[i] >> shift) & bw_mask(bw - shift)) - (u64(1) << (bw - shift)) * aw[i]) & mask;
-  if (signed_arith && party == kAlice) o = (o - (u64(1) << (bw - shift - 1))) & mask;
-  if (heuristic && party != kAlice) o = (o - (u64(1) << (bw - 3 - shift))) & mask;
-  out[i] = o;
+  u64 a[2], w[2], o[2];
+  load_elems<V>(adj, i, pair, a);
+  load_elems<V>(aw, i, pair, w);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    o[e] = (((a[e] >> shift) & bw_mask(bw - shift)) - (u64(1) << (bw - shift)) * w[e]) & mask;
+    if (signed_arith && party == kAlice) o[e] = (o[e] - (u64(1) << (bw - shift - 1))) & mask;
+    if (heuristic && party != kAlice) o[e] = (o[e] - (u64(1) << (bw - 3 - shift))) & mask;
+  }
+  store_elems<V>(out, i, pair, o);
 }
 // Truncation::truncate_and_reduce (truncation.cpp:289-317): aw == nullptr gives the operand of
 // wrap_computation (:300-304), else the result in the smaller ring (:311-313)
@@ -264,6 +335,22 @@ using namespace mmh;
     int rc_ = (x);       \
     if (rc_) return rc_; \
   } while (0)
+// every array 16-byte aligned, the bit array 2-byte (null ones do not count): two elements per lane
+static bool aligned_pairs(std::initializer_list<const void *> ptrs, const void *bit_array = nullptr) {
+  uintptr_t bits = 0;
+  for (const void *p : ptrs) bits |= (uintptr_t)p;
+  return (bits & 15) == 0 && ((uintptr_t)bit_array & 1) == 0;
+}
+#define LAUNCH_PAIRS(kern2, kern1, n, s, ptrs, ...)                                                                \
+  do {                                                                                                             \
+    if ((n) > 0) {                                                                                                 \
+      if (aligned_pairs ptrs)                                                                                      \
+        hipLaunchKernelGGL((kern2), dim3(nblocks(((n) + 1) / 2)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__);    \
+      else                                                                                                         \
+        hipLaunchKernelGGL((kern1), dim3(nblocks(n)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__);                \
+      MMH_HIP(hipGetLastError());                                                                                  \
+    }                                                                                                              \
+  } while (0)
 #define LAUNCH1D(kern, n, s, ...)                                                          \
   do {                                                                                     \
     if ((n) > 0) {                                                                         \
@@ -277,7 +364,8 @@ extern "C" int mmh_r2f_pre(int party, const uint64_t *d_in, size_t n, int bw, ui
   CHECK_RC(check_common(party, n, d_in, d_tmp, d_msb));
   MMH_REQUIRE(bw >= 2 && bw <= 64 && p >= 2, MMH_ERR_INVALID_ARG);
   const u64 mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
-  LAUNCH1D(pre_kernel<0>, n, stream, party, d_in, n, bw, p, mask % p + 1, 0, d_tmp, d_msb, d_corr);
+  LAUNCH_PAIRS((pre_kernel<0, 2>), (pre_kernel<0, 1>), n, stream, ({d_in, d_tmp, d_corr}, d_msb), party, d_in, n, bw, p,
+               mask % p + 1, 0, d_tmp, d_msb, d_corr);
   return MMH_OK;
 }
 extern "C" int mmh_r2f_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
@@ -286,15 +374,16 @@ extern "C" int mmh_r2f_post(int party, const uint64_t *d_tmp, const uint8_t *d_m
   MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(bw >= 2 && bw <= 64 && p >= 2, MMH_ERR_INVALID_ARG);
   const u64 mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
-  LAUNCH1D(r2f_post_kernel, n, stream, party, d_tmp, d_msb, d_y, n, p, mask % p + 1, (u64(1) << (bw - 2)) % p,
-           d_out);
+  LAUNCH_PAIRS(r2f_post_kernel<2>, r2f_post_kernel<1>, n, stream, ({d_tmp, d_y, d_out}, d_msb), party, d_tmp, d_msb,
+               d_y, n, p, mask % p + 1, (u64(1) << (bw - 2)) % p, d_out);
   return MMH_OK;
 }
 extern "C" int mmh_f2r_pre(int party, const uint64_t *d_in, size_t n, uint64_t p, int shift, uint64_t *d_tmp,
                            uint8_t *d_msb, uint64_t *d_corr, void *stream) {
   CHECK_RC(check_common(party, n, d_in, d_tmp, d_msb));
   MMH_REQUIRE(p >= 4 && shift >= 0 && shift < 64, MMH_ERR_INVALID_ARG);
-  LAUNCH1D(pre_kernel<1>, n, stream, party, d_in, n, 0, p, p >> shift, 0, d_tmp, d_msb, d_corr);
+  LAUNCH_PAIRS((pre_kernel<1, 2>), (pre_kernel<1, 1>), n, stream, ({d_in, d_tmp, d_corr}, d_msb), party, d_in, n, 0, p,
+               p >> shift, 0, d_tmp, d_msb, d_corr);
   return MMH_OK;
 }
 extern "C" int mmh_f2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
@@ -302,7 +391,8 @@ extern "C" int mmh_f2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_m
   CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
   MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(bw >= 1 && bw <= 64 && p >= 4, MMH_ERR_INVALID_ARG);
-  LAUNCH1D(f2r_post_kernel, n, stream, party, d_tmp, d_msb, d_y, n, p, bw, 0, 0, d_out);
+  LAUNCH_PAIRS(f2r_post_kernel<2>, f2r_post_kernel<1>, n, stream, ({d_tmp, d_y, d_out}, d_msb), party, d_tmp, d_msb,
+               d_y, n, p, bw, 0, 0, d_out);
   return MMH_OK;
 }
 extern "C" int mmh_f2r_trunc_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
@@ -310,14 +400,16 @@ extern "C" int mmh_f2r_trunc_post(int party, const uint64_t *d_tmp, const uint8_
   CHECK_RC(check_common(party, n, d_tmp, d_msb, d_y));
   MMH_REQUIRE(n == 0 || d_out, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(bw >= 1 && bw <= 64 && p >= 4 && shift >= 0 && shift < 64, MMH_ERR_INVALID_ARG);
-  LAUNCH1D(f2r_post_kernel, n, stream, party, d_tmp, d_msb, d_y, n, p, bw, shift, 1, d_out);
+  LAUNCH_PAIRS(f2r_post_kernel<2>, f2r_post_kernel<1>, n, stream, ({d_tmp, d_y, d_out}, d_msb), party, d_tmp, d_msb,
+               d_y, n, p, bw, shift, 1, d_out);
   return MMH_OK;
 }
 extern "C" int mmh_r2r_pre(int party, const uint64_t *d_in, size_t n, int bw_a, uint64_t *d_tmp, uint8_t *d_msb,
                            uint64_t *d_corr, void *stream) {
   CHECK_RC(check_common(party, n, d_in, d_tmp, d_msb));
   MMH_REQUIRE(bw_a >= 2 && bw_a <= 64, MMH_ERR_INVALID_ARG);
-  LAUNCH1D(pre_kernel<0>, n, stream, party, d_in, n, bw_a, 2, 0, 1, d_tmp, d_msb, d_corr);
+  LAUNCH_PAIRS((pre_kernel<0, 2>), (pre_kernel<0, 1>), n, stream, ({d_in, d_tmp, d_corr}, d_msb), party, d_in, n, bw_a,
+               2, 0, 1, d_tmp, d_msb, d_corr);
   return MMH_OK;
 }
 extern "C" int mmh_r2r_post(int party, const uint64_t *d_tmp, const uint8_t *d_msb, const uint64_t *d_y,
@@ -342,7 +434,8 @@ extern "C" int mmh_trunc_pre(int party, const uint64_t *d_in, size_t n, int bw, 
   MMH_REQUIRE(party == 1 || party == 2, MMH_ERR_INVALID_ARG);
   MMH_REQUIRE(n == 0 || (d_in && d_adj), MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(bw >= (heuristic ? 4 : 2) && bw <= 64, MMH_ERR_INVALID_ARG);
-  LAUNCH1D(trunc_pre_kernel, n, stream, party, d_in, n, bw, signed_arith, heuristic, d_adj, d_cmp);
+  LAUNCH_PAIRS(trunc_pre_kernel<2>, trunc_pre_kernel<1>, n, stream, ({d_in, d_adj, d_cmp}), party, d_in, n, bw,
+               signed_arith, heuristic, d_adj, d_cmp);
   return MMH_OK;
 }
 extern "C" int mmh_trunc_post(int party, const uint64_t *d_adj, const uint64_t *d_aw, size_t n, int shift, int bw,
@@ -352,7 +445,8 @@ extern "C" int mmh_trunc_post(int party, const uint64_t *d_adj, const uint64_t *
   // the reference's asserts (truncation-cheetah.cpp:12-13); the heuristic's offset 2^(bw-3-shift) must exist
   MMH_REQUIRE(bw >= 2 && bw <= 64 && shift >= 1 && bw - shift > 0 && (!heuristic || shift <= bw - 3),
               MMH_ERR_INVALID_ARG);
-  LAUNCH1D(trunc_post_kernel, n, stream, party, d_adj, d_aw, n, shift, bw, signed_arith, heuristic, d_out);
+  LAUNCH_PAIRS(trunc_post_kernel<2>, trunc_post_kernel<1>, n, stream, ({d_adj, d_aw, d_out}), party, d_adj, d_aw, n,
+               shift, bw, signed_arith, heuristic, d_out);
   return MMH_OK;
 }
 extern "C" int mmh_trunc_reduce_pre(const uint64_t *d_in, size_t n, int shift, uint64_t *d_lower, void *stream) {

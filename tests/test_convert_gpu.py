@@ -36,12 +36,13 @@ def run_pre_post(mm, kind, party, x, y, **kw):
     import torch
     from openmm_amd.lib import check, dptr, load_library
     lib = load_library()
-    n = len(x)
-    d_in, d_y = dev(x), dev(y)
-    tmp = torch.empty(n, dtype=torch.int64, device="cuda")
-    msb = torch.empty(n, dtype=torch.uint8, device="cuda")
-    corr = torch.zeros(n, dtype=torch.int64, device="cuda")
-    out = torch.empty((n, 2) if kind == "r2r128" else n, dtype=torch.int64, device="cuda")
+    n, skew = len(x), kw.get("skew", 0)   # skew 1: every array starts one element into its allocation (8 mod 16)
+    pad = np.zeros(skew, np.uint64)
+    d_in, d_y = dev(np.concatenate([pad, x]))[skew:], dev(np.concatenate([pad, y]))[skew:]
+    tmp = torch.empty(n + skew, dtype=torch.int64, device="cuda")[skew:]
+    msb = torch.empty(n + skew, dtype=torch.uint8, device="cuda")[skew:]
+    corr = torch.zeros(n + skew, dtype=torch.int64, device="cuda")[skew:]
+    out = torch.empty((n + skew, 2) if kind == "r2r128" else n + skew, dtype=torch.int64, device="cuda")[skew:]
     if kind == "r2f":
         check(lib.mmh_r2f_pre(party, dptr(d_in), n, kw["bw"], kw["p"], dptr(tmp), dptr(msb), dptr(corr), None))
         check(lib.mmh_r2f_post(party, dptr(tmp), dptr(msb), dptr(d_y), n, kw["bw"], kw["p"], dptr(out), None))
@@ -100,6 +101,32 @@ def test_field_to_ring_kernels(mm, party, bw, shift):
     assert np.array_equal(g[0], tmp) and np.array_equal(g[1], msb) and np.array_equal(g[3], out)
     if party == 1:
         assert np.array_equal(g[2], corr)
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 513, 19999])
+@pytest.mark.parametrize("skew", [0, 1])
+def test_conversion_kernels_odd_lengths_and_alignment(mm, n, skew):
+    """the kernels take two elements per lane when their arrays are 16-byte aligned and one otherwise: odd lengths
+    (the last lane does one) and arrays at 8 mod 16 give the same bits"""
+    o, p, bw = load(), PRIMES[37], 37
+    for party in (1, 2):
+        x, y = edge_mix(max(n, 10), 1 << bw, SEED + 50)[:n], edge_mix(max(n, 10), p, SEED + 51)[:n]
+        tmp, msb, corr, out = (np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint64),
+                               np.zeros(n, np.uint64))
+        o.mmo_r2f_pre(party, A(x), n, bw, p, A(tmp), A(msb), A(corr))
+        o.mmo_r2f_post(party, A(tmp), A(msb), A(y), n, bw, p, A(out))
+        g = run_pre_post(mm, "r2f", party, x, y, bw=bw, p=p, skew=skew)
+        assert np.array_equal(g[0], tmp) and np.array_equal(g[1], msb) and np.array_equal(g[3], out)
+        assert party == 2 or np.array_equal(g[2], corr)
+        for shift in (0, 12):
+            o.mmo_f2r_pre(party, A(y), n, p, shift, A(tmp), A(msb), A(corr))
+            if shift:
+                o.mmo_f2r_trunc_post(party, A(tmp), A(msb), A(x), n, p, bw, shift, A(out))
+            else:
+                o.mmo_f2r_post(party, A(tmp), A(msb), A(x), n, p, bw, A(out))
+            g = run_pre_post(mm, "f2r", party, y, x, bw=bw, p=p, shift=shift, skew=skew)
+            assert np.array_equal(g[0], tmp) and np.array_equal(g[1], msb) and np.array_equal(g[3], out)
+            assert party == 2 or np.array_equal(g[2], corr)
 
 
 @pytest.mark.parametrize("party", [1, 2])

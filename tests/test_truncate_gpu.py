@@ -45,6 +45,15 @@ def test_truncate_kernels(mm, party, signed_arith, heuristic, bw, shift):
                              None))
     assert np.array_equal(host(d_adj), adj) and np.array_equal(host(d_cmp), cmp)
     assert np.array_equal(host(d_out), out)
+    # an odd length at 8 mod 16 (the one-element-per-lane kernels) and at 0 mod 16 (pairs, the last lane one)
+    for lo in (1, 2):
+        m = n - 1 - lo
+        e_adj, e_cmp, e_out = (torch.empty(n, dtype=torch.int64, device="cuda")[lo:] for _ in range(3))
+        check(lib.mmh_trunc_pre(party, dptr(d_x[lo:]), m, bw, signed_arith, heuristic, dptr(e_adj), dptr(e_cmp), None))
+        check(lib.mmh_trunc_post(party, dptr(e_adj), dptr(d_aw[lo:]), m, shift, bw, signed_arith, heuristic,
+                                 dptr(e_out), None))
+        assert np.array_equal(host(e_adj)[:m], adj[lo:lo + m]) and np.array_equal(host(e_cmp)[:m], cmp[lo:lo + m])
+        assert np.array_equal(host(e_out)[:m], out[lo:lo + m])
 
 
 @pytest.mark.parametrize("bw,shift", [(32, 12), (41, 1), (64, 20), (64, 63)])
