@@ -243,6 +243,7 @@ __device__ __forceinline__ u64 reduce64(u64 a, const DevMod &m) {
 // The opaque context of the C ABI.
 struct mmh_ctx {
   int device = 0;
+  int n_cu = 256;   // compute units of the device (grid size of the persistent product kernel)
   size_t N = 0;
   int logN = 0;
   size_t L = 0;

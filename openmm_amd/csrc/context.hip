@@ -244,6 +244,8 @@ extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t
   if (scope.rc) MMH_FAIL(scope.rc, "cannot make device " + std::to_string(device) + " current");
   mmh_ctx *ctx = new mmh_ctx();
   ctx->device = device;
+  if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cu <= 0)
+    ctx->n_cu = 256;
   ctx->N = N;
   ctx->logN = logN;
   ctx->L = L;

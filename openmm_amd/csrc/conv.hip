@@ -616,16 +616,18 @@ __device__ __forceinline__ void fold_words(u32 &w0, u32 &w1, u32 &w2, u32 w3, u3
   w0 = lo32(t0), w1 = lo32(m1), w2 = hi32(t1) + hi32(m1);
 }
 
-// A workgroup of 8 waves owns 128 filters x 64 columns; wave (wm, wn) owns filters 64 wm .. +63 (4 tiles of 16)
-// and columns 16 wn .. +15.  Per 64-channel step the 32 KiB of column digits and 16/24 KiB of weight digits are
+// A workgroup of 8 waves works on an item of (at most) 128 filters x 64 columns at a time (PwItems below); wave
+// (wm, wn) owns half of the item's filters (4, 2 or 1 tiles of 16) and columns 16 wn .. +15.  Per 64-channel step the 32 KiB of column digits and 16/24 KiB of weight digits are
 // copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging registers; both images are
 // already in fragment order, lane l reads unit l, conflict free) into one of two buffers while the products of
 // earlier steps run: three buffers, two steps in flight, one raw barrier per step (two buffers and one step in
 // flight when the weights need a third digit).  Ten i32 accumulator tiles per filter tile, one per power of
 // 256, started at 2^28 so that the sums stay positive.
-// Workgroups are dealt to the XCDs round robin by the dispatcher; the index arithmetic below gives each XCD
-// whole column tiles, all of whose filter tiles then stream the same digits (measured within 3 % of the plain
-// order: the digit image sits in the Infinity Cache either way).
+// (Giving each XCD whole column tiles, all of whose filter blocks then stream the same digits through one L2, measured
+// within 3 % of the plain order: the digit image sits in the Infinity Cache either way.)
+// Where the time goes, 256 -> 256 3x3 at 14x14 (36 steps, 88 us): with the copies switched off 73 us, with the
+// products switched off 54 us (48 KiB per step and compute unit = 10 TB/s over the chip), with both 8 us; one step
+// takes 2.0 us against 0.85 us of matrix-core issue at the nominal clock.
 // The rare form inside the product kernel: some weight of the layer is 2^20 or more in magnitude, so the byte-digit
 // product does not apply and the workgroup computes its 128 filters x 64 columns on the vector ALU from the lifted
 // 64-bit weights, exactly as pw_gemm_kernel<false> does (lazy 128-bit sums reduced every 8 taps, canonical results).
@@ -670,37 +672,75 @@ __device__ __noinline__ void pw_general_tile(const u64 *__restrict__ image, cons
     if (mbase + j < M) acc[(size_t)(mbase + j) * cols + col] = x0[j];
 }
 
+// The work of one launch as a list of items, item = one live 64-column tile x a block of filters.  The launch has one
+// workgroup per compute unit (at most), workgroup b takes items b, b + G, b + 2G, ...: the copies of an item's first
+// steps are issued while the previous item's last products and its epilogue run, and no workgroup is started or retired
+// between items (against one workgroup per item: 1024 -> 256 1x1 at 14x14 58 -> 45 us, 256 -> 256 3x3 114 -> 88 us,
+// 512 -> 2048 1x1 at 7x7 176 -> 161 us; layers of few steps and many items, 256 -> 1024 1x1, stay where they were).
+// Main items hold F filters (128; 64 or 32 when the layer has no more, so that both wave rows work); the items left
+// over after the last full round of G are cut into s = 2 or 4 pieces of F / s filters when that many more workgroups
+// find a free compute unit, which shortens the last round instead of leaving most of the chip idle in it.
+struct PwItems {
+  int n_main;    // items of F filters: index -> (slot = index / MTm, filter block index % MTm)
+  int n_items;   // n_main + (left over) << s_log
+  int MTm;       // filter blocks of F per column tile
+  int F_log;     // 7, 6 or 5
+  int s_log;     // 0, 1 or 2
+};
+static PwItems pw_items(int n_live, int M, int n_cu) {
+  PwItems it;
+  it.F_log = M <= 32 ? 5 : M <= 64 ? 6 : 7;
+  it.MTm = (M + (1 << it.F_log) - 1) >> it.F_log;
+  const int items = n_live * it.MTm;
+  const int rem = items < n_cu ? items : items % n_cu;
+  it.n_main = items - rem;
+  it.s_log = 0;
+  while (it.s_log < 2 && it.F_log - (it.s_log + 1) >= 5 && (rem << (it.s_log + 1)) <= n_cu) ++it.s_log;
+  it.n_items = it.n_main + (rem << it.s_log);
+  return it;
+}
+
 constexpr int kPwLdsBytes = 3 * (2048 + 1024) * 16;   // 144 KiB: three buffers of 2 weight digits (two of 3 fit too)
 __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ u8, const uint4 *__restrict__ w8,
                                                       const u32 *__restrict__ flag, const int *__restrict__ live,
-                                                      u64 *__restrict__ acc, int M, int MT, int KC, int n_live,
-                                                      size_t S, int logN, const DevMod *__restrict__ mods,
+                                                      u64 *__restrict__ acc, int M, int KC, int n_live, size_t S,
+                                                      int logN, const DevMod *__restrict__ mods,
                                                       const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
-                                                      const u64 *__restrict__ wl, int Mpad, int Cpad) {
+                                                      const u64 *__restrict__ wl, int Mpad, int Cpad, PwItems items) {
   extern __shared__ uint4 pw_lds[];
-  const int seq = blockIdx.x >> 3, slot = (seq / MT) * 8 + (blockIdx.x & 7), mt = seq % MT;
-  if (slot >= n_live) return;
-  const u32 fl = *flag;                 // both loads in flight together: a workgroup has the CU to itself, so every
-  const int tile = live[slot];          // dependent load at its start is exposed latency
-  if (fl & 1u) {                        // weights of 2^20 and more: the lifted form (rare)
-    pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)tile * 64, mt);
+  const u32 fl = *flag;
+  const int G = (int)gridDim.x;
+  if (fl & 1u) {                        // weights of 2^20 and more: the lifted form (rare), 128 filters per item
+    const int MT = (M + 127) >> 7;
+    for (int idx = blockIdx.x; idx < n_live * MT; idx += G)
+      pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)live[idx / MT] * 64, idx % MT);
     return;
   }
   const int nA = (fl & 2u) ? 3 : 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int N = 1 << logN;
-  const size_t cols = S * 4 * N, c0 = (size_t)tile * 64;
-  const size_t col = c0 + wn * 16 + (lane & 15);
-  const int mrow = mt * 128 + wm * 64 + (lane >> 4) * 4;   // + 16*ms + r
-  // 16-filter tiles of this wave that hold a filter at all (wave-uniform; 4 except in the layer's last 128-filter tile)
-  const int ms_used = __builtin_amdgcn_readfirstlane(min(4, max(0, (M - (mt * 128 + wm * 64) + 15) / 16)));
-  const int l = (int)((c0 >> logN) & 1);
-  const DevMod q = mods[l];             // for the epilogue; loaded here so that its latency hides behind the products
-  const uint4 *__restrict__ gB = u8 + (size_t)slot * KC * 2048 + lane;
-  const uint4 *__restrict__ gA = w8 + (size_t)mt * KC * 1536 + lane;
+  const size_t cols = S * 4 * N;
   const int stride = 2048 + 512 * nA, nbuf = nA == 2 ? 3 : 2;   // uint4 per buffer: column digits, weight digits
   const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) void *)pw_lds;
+  // item index -> column-tile slot and first filter; false past the layer's last filter (pieces of the last block)
+  const int F = 1 << items.F_log, f_sub = F >> items.s_log;
+  auto decode = [&](int it, int &slot, int &fb, int &f) {
+    int idx = it, part = 0;
+    f = F;
+    if (it >= items.n_main) {
+      const int j = it - items.n_main;
+      idx = items.n_main + (j >> items.s_log), part = j & ((1 << items.s_log) - 1), f = f_sub;
+    }
+    slot = idx / items.MTm;
+    fb = (idx % items.MTm) * F + part * f;
+    return fb < M;
+  };
+  auto next_item = [&](int it) {
+    int slot, fb, f;
+    while (it < items.n_items && !decode(it, slot, fb, f)) it += G;
+    return it;
+  };
   // One 1 KiB copy global -> LDS: lane l's 16 bytes land at dst + 16 l.  Inline asm so that hipcc neither counts
   // the copy nor drains it before the next LDS read; the waits below count them.
   auto glds16 = [&](const uint4 *src, u32 dst_unit) {
@@ -711,109 +751,138 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
                  : "v"(src), "s"(dst)
                  : "memory");
   };
-  auto stage = [&](int kc, int buf) {   // this wave's share: 4 KiB of column digits, 1 KiB per weight digit
-    const u32 unit0 = (u32)(buf * stride) / 64;
+  // The copies run ahead of the products over item boundaries: (s_it, s_kc) is the next step to copy, `staged` counts
+  // the steps copied so far and `done` the steps multiplied (both by this workgroup; buffer = count mod nbuf).
+  int s_it = next_item((int)blockIdx.x), s_kc = 0, s_buf = 0, staged = 0, done = 0;
+  const uint4 *gB = u8 + lane, *gA = w8 + lane;
+  auto stager_item = [&]() {
+    int slot, fb, f;
+    if (s_it < items.n_items && decode(s_it, slot, fb, f)) {
+      gB = u8 + (size_t)slot * KC * 2048 + lane;
+      gA = w8 + (size_t)(fb >> 7) * KC * 1536 + lane;
+    }
+  };
+  stager_item();
+  auto stage_next = [&]() {   // this wave's share of one step: 4 KiB of column digits, 1 KiB per weight digit
+    if (s_it >= items.n_items) return;
+    const u32 unit0 = (u32)(s_buf * stride) / 64;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) glds16(gB + (size_t)kc * 2048 + (wave * 4 + r) * 64, unit0 + wave * 4 + r);
+    for (int r = 0; r < 4; ++r) glds16(gB + (size_t)s_kc * 2048 + (wave * 4 + r) * 64, unit0 + wave * 4 + r);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-      if (a < nA) glds16(gA + (size_t)kc * 1536 + (a * 8 + wave) * 64, unit0 + 32 + a * 8 + wave);
+      if (a < nA) glds16(gA + (size_t)s_kc * 1536 + (a * 8 + wave) * 64, unit0 + 32 + a * 8 + wave);
+    ++staged;
+    s_buf = s_buf + 1 == nbuf ? 0 : s_buf + 1;
+    if (++s_kc == KC) {
+      s_kc = 0, s_it = next_item(s_it + G);
+      stager_item();
+    }
   };
-  v4i sum[4][10];
+  for (int i = 0; i + 1 < nbuf; ++i) stage_next();
+  int cur = 0;                     // buffer of the step being multiplied
+  for (int c_it = next_item((int)blockIdx.x); c_it < items.n_items; c_it = next_item(c_it + G)) {
+    int slot, fb, f;
+    decode(c_it, slot, fb, f);
+    const int tile = live[slot];
+    const int msn = f >> 5;                                       // 16-filter tiles per wave: 4, 2 or 1
+    const int wfb = fb + wm * (f >> 1);                           // this wave's first filter
+    const int u0 = __builtin_amdgcn_readfirstlane(((fb & 127) >> 4) + wm * msn);   // ... its unit in the 128-filter block
+    // tiles of this wave that hold a filter at all (wave-uniform; fewer only in the layer's last block)
+    const int ms_used = __builtin_amdgcn_readfirstlane(min(msn, max(0, (M - wfb + 15) / 16)));
+    v4i sum[4][10];
 #pragma unroll
-  for (int ms = 0; ms < 4; ++ms)
+    for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-    for (int d = 0; d < 10; ++d) sum[ms][d] = v4i{1 << 28, 1 << 28, 1 << 28, 1 << 28};
-  stage(0, 0);
-  if (nbuf == 3 && KC > 1) stage(1, 1);
-  int cur = 0;                     // buffer of step kc
-  for (int kc = 0; kc < KC; ++kc) {
-    // step kc has landed (this wave's copies; the barrier covers the others'), a later step may stay in flight;
-    // past the barrier every wave is done with the buffer of step kc - 1, which the new copies overwrite.
-    // A raw barrier: __syncthreads() would drain the copies in flight.
-    if (nbuf == 3 && kc + 1 < KC)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 4 + 2 copies per wave and step
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const int ahead = kc + nbuf - 1;
-    if (ahead < KC) {
-      int buf = cur + nbuf - 1;
-      if (buf >= nbuf) buf -= nbuf;
-      stage(ahead, buf);
-    }
-    const uint4 *ldsB = pw_lds + cur * stride, *ldsA = ldsB + 2048;
-    cur = cur + 1 == nbuf ? 0 : cur + 1;
-    v4i b[8];
+      for (int d = 0; d < 10; ++d) sum[ms][d] = v4i{1 << 28, 1 << 28, 1 << 28, 1 << 28};
+    for (int kc = 0; kc < KC; ++kc) {
+      // This step has landed (this wave's copies; the barrier covers the others'), a later step may stay in flight:
+      // when one was copied after it, at least 4 + nA operations are younger than this step's copies (an epilogue's
+      // stores may be too, which only makes the wait longer).  Past the barrier every wave is done with the buffer of
+      // the step before, which the new copies overwrite.  A raw barrier: __syncthreads() would drain the copies.
+      if (nbuf == 3 && staged - done >= 2)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 4 + 2 copies per wave and step
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_next();   // (issuing the pieces between the groups of products instead measured the same)
+      const uint4 *ldsB = pw_lds + cur * stride, *ldsA = ldsB + 2048;
+      cur = cur + 1 == nbuf ? 0 : cur + 1;
+      ++done;
+      v4i b[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint4 t = ldsB[(j * 4 + wn) * 64 + lane];
-      b[j] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-    }
+      for (int j = 0; j < 8; ++j) {
+        const uint4 t = ldsB[(j * 4 + wn) * 64 + lane];
+        b[j] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+      }
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      if (ms >= ms_used) break;   // filter tiles past the layer's last filter (layers with few filters): no products
+      for (int ms = 0; ms < 4; ++ms) {
+        if (ms >= ms_used) break;   // filter tiles past the wave's share or the layer's last filter: no products
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        if (a < nA) {
-          const uint4 t = ldsA[(a * 8 + wm * 4 + ms) * 64 + lane];
-          const v4i av = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        for (int a = 0; a < 3; ++a) {
+          if (a < nA) {
+            const uint4 t = ldsA[(a * 8 + u0 + ms) * 64 + lane];
+            const v4i av = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            sum[ms][a + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], sum[ms][a + j], 0, 0, 0);
+            for (int j = 0; j < 8; ++j)
+              sum[ms][a + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], sum[ms][a + j], 0, 0, 0);
+          }
         }
       }
     }
-  }
-  // value = sum_d (sum[d] - 2^28) 256^d, signed, below 2^100 in magnitude.  Assemble the biased digits into
-  // 128 bits, add k*q - bias (k*q in [2^101, 2^102)) to land on a non-negative representative below 2^103,
-  // then reduce: two folds of q = 2^b - c where the modulus has that shape, else Barrett.
-  const u32 qbits = 64 - (u32)__builtin_clzll(q.q), sh = 102 - qbits;   // q << sh in [2^101, 2^102)
-  const u64 kq_lo = q.q << sh, kq_hi = q.q >> (64 - sh);
-  const u64 off_lo = kq_lo - 0x1010101010000000ull, off_hi = kq_hi - 0x1010101010ull - (kq_lo < 0x1010101010000000ull);
-  const u32 fb = q.fold_shift + 32, fc = q.fold_c;
-  // fold bounds: x < 2^103 -> x1 < 2^b + 2^(103-b) c (bits1 bits) -> x2 < 2^b + (x1 >> b) c (bits2 bits, must fit a word)
-  bool folds = fc != 0 && fb >= 40 && fb <= 62;
-  if (folds) {
-    const u32 cb = 32 - (u32)__builtin_clz(fc);
-    const u32 bits1 = max(fb, 103 - fb + cb) + 1;
-    const u32 bits2 = max(fb, bits1 - fb + cb) + 1;
-    folds = bits1 <= 64 + fb && bits2 <= 64;
-  }
-  // (the epilogue is written on 32-bit words with v_mad_u64_u32 and funnel shifts; hipcc's 64-bit shifts by a
-  // register amount and its 128-bit adds made it a tenth of the kernel)
-  const u32 o0 = lo32(off_lo), o1 = hi32(off_lo), o2 = lo32(off_hi), o3 = hi32(off_hi);
-  const u32 fs = q.fold_shift, fmask = q.fold_mask;
-  u64 *__restrict__ out = acc + (size_t)mrow * cols + col;
-#pragma unroll
-  for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (ms >= ms_used) continue;
-      u32 p[10];
-#pragma unroll
-      for (int d = 0; d < 10; ++d) p[d] = (u32)sum[ms][d][r];
-      const u64 lo = mad32(p[3], 1u << 24, mad32(p[2], 1u << 16, mad32(p[1], 1u << 8, p[0])));
-      const u64 mid = mad32(p[7], 1u << 24, mad32(p[6], 1u << 16, mad32(p[5], 1u << 8, p[4])));
-      const u64 top = mad32(p[9], 1u << 8, p[8]);
-      // lo + mid 2^32 + top 2^64 + offset, word by word
-      const u64 a0 = (u64)lo32(lo) + o0;
-      const u64 a1 = (u64)hi32(lo) + lo32(mid) + o1 + hi32(a0);
-      const u64 a2 = (u64)hi32(mid) + lo32(top) + o2 + hi32(a1);
-      u32 w0 = lo32(a0), w1 = lo32(a1), w2 = lo32(a2);
-      const u32 w3 = hi32(top) + o3 + hi32(a2);
-      u64 v;
-      if (folds) {
-        fold_words(w0, w1, w2, w3, fc, fs, fmask);
-        fold_words(w0, w1, w2, 0, fc, fs, fmask);
-        v = csub(fold_mod(make64(w0, w1), fc, fs, fmask), q.q);
-      } else {
-        v = reduce128_wide(make64(w2, w3), make64(w0, w1), q);
-      }
-      if (mrow + 16 * ms + r < M) out[(size_t)(16 * ms + r) * cols] = v;
+    const size_t c0 = (size_t)tile * 64;
+    const size_t col = c0 + wn * 16 + (lane & 15);
+    const int mrow = wfb + (lane >> 4) * 4;   // + 16*ms + r
+    const DevMod q = mods[(int)((c0 >> logN) & 1)];
+    // value = sum_d (sum[d] - 2^28) 256^d, signed, below 2^100 in magnitude.  Assemble the biased digits into
+    // 128 bits, add k*q - bias (k*q in [2^101, 2^102)) to land on a non-negative representative below 2^103,
+    // then reduce: two folds of q = 2^b - c where the modulus has that shape, else Barrett.
+    const u32 qbits = 64 - (u32)__builtin_clzll(q.q), sh = 102 - qbits;   // q << sh in [2^101, 2^102)
+    const u64 kq_lo = q.q << sh, kq_hi = q.q >> (64 - sh);
+    const u64 off_lo = kq_lo - 0x1010101010000000ull, off_hi = kq_hi - 0x1010101010ull - (kq_lo < 0x1010101010000000ull);
+    const u32 fbits = q.fold_shift + 32, fc = q.fold_c;
+    // fold bounds: x < 2^103 -> x1 < 2^b + 2^(103-b) c (bits1 bits) -> x2 < 2^b + (x1 >> b) c (bits2 bits, must fit a word)
+    bool folds = fc != 0 && fbits >= 40 && fbits <= 62;
+    if (folds) {
+      const u32 cb = 32 - (u32)__builtin_clz(fc);
+      const u32 bits1 = max(fbits, 103 - fbits + cb) + 1;
+      const u32 bits2 = max(fbits, bits1 - fbits + cb) + 1;
+      folds = bits1 <= 64 + fbits && bits2 <= 64;
     }
+    // (the epilogue is written on 32-bit words with v_mad_u64_u32 and funnel shifts; hipcc's 64-bit shifts by a
+    // register amount and its 128-bit adds made it a tenth of the kernel)
+    const u32 o0 = lo32(off_lo), o1 = hi32(off_lo), o2 = lo32(off_hi), o3 = hi32(off_hi);
+    const u32 fs = q.fold_shift, fmask = q.fold_mask;
+    u64 *__restrict__ out = acc + (size_t)mrow * cols + col;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (ms >= ms_used) continue;
+        u32 p[10];
+#pragma unroll
+        for (int d = 0; d < 10; ++d) p[d] = (u32)sum[ms][d][r];
+        const u64 lo = mad32(p[3], 1u << 24, mad32(p[2], 1u << 16, mad32(p[1], 1u << 8, p[0])));
+        const u64 mid = mad32(p[7], 1u << 24, mad32(p[6], 1u << 16, mad32(p[5], 1u << 8, p[4])));
+        const u64 top = mad32(p[9], 1u << 8, p[8]);
+        // lo + mid 2^32 + top 2^64 + offset, word by word
+        const u64 a0 = (u64)lo32(lo) + o0;
+        const u64 a1 = (u64)hi32(lo) + lo32(mid) + o1 + hi32(a0);
+        const u64 a2 = (u64)hi32(mid) + lo32(top) + o2 + hi32(a1);
+        u32 w0 = lo32(a0), w1 = lo32(a1), w2 = lo32(a2);
+        const u32 w3 = hi32(top) + o3 + hi32(a2);
+        u64 v;
+        if (folds) {
+          fold_words(w0, w1, w2, w3, fc, fs, fmask);
+          fold_words(w0, w1, w2, 0, fc, fs, fmask);
+          v = csub(fold_mod(make64(w0, w1), fc, fs, fmask), q.q);
+        } else {
+          v = reduce128_wide(make64(w2, w3), make64(w0, w1), q);
+        }
+        if (mrow + 16 * ms + r < M) out[(size_t)(16 * ms + r) * cols] = v;
+      }
+  }
 }
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
@@ -878,7 +947,7 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
   const bool mfma = pw_mfma_enabled(ctx);
   if (mfma && form != 1) {
     // fast form on the matrix cores: byte digits of the rotated columns once, then the i8 products
-    const int KC = z.Cpad64 / 64, MT = z.Mpad128 / 128, n_live = (int)p->pw_live_tiles;
+    const int KC = z.Cpad64 / 64, n_live = (int)p->pw_live_tiles;
     void *u8 = nullptr;
     if (scratch_alloc(&u8, (size_t)n_live * KC * 32768, s) != hipSuccess) {
       set_error("pointwise_product: allocation failed");
@@ -889,9 +958,10 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
                        p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter,
                        fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0});
     if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
-    hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)((n_live + 7) / 8 * 8 * MT)), dim3(512), kPwLdsBytes, s,
-                       (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, MT, KC, n_live, S,
-                       ctx->logN, ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad);
+    const PwItems items = pw_items(n_live, z.M, ctx->n_cu);
+    hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
+                       (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_live, S, ctx->logN,
+                       ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items);
     (void)scratch_free(u8, s);
   }
   // (on the matrix-core path the product kernel carries the lifted-weight form as a branch of its own)
