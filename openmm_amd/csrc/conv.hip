@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ 
                                                         const int *__restrict__ live, uint4 *__restrict__ u8,
                                                         const u32 *__restrict__ flag, int KC, size_t S, int logN,
                                                         const u32 *__restrict__ nzmap, int M,
-                                                        u32 *__restrict__ zero_filter, PwFold fold) {
+                                                        u32 *__restrict__ zero_filter, PwFold fold, int skip7) {
   // conv2DOneFilter :573-580: some filter all zero mod t?  One workgroup reads the map pw_weights_kernel left.
   if (nzmap && blockIdx.x == 0 && blockIdx.y == 0) {
     int bad = 0;
@@ -583,6 +583,8 @@ __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ 
     const u64 d = (v + kDigitBias) ^ kDigitBias;
     lo[k] = (u32)d, hi[k] = (u32)(d >> 32);
   }
+  // (modulus below 2^54: the top digit of every value and of every negation is 0, the product kernel leaves it out)
+  const int nplanes = (skip7 >> (pl & 1)) & 1 ? 7 : 8;
   // byte j of the 16 values -> 16 bytes: 4x4 byte transposes
   uint4 *__restrict__ out = u8 + (((size_t)blockIdx.x * KC + kc) * 8 * 4 + (col >> 4)) * 64 + ((kg << 4) | (col & 15));
   auto planes = [&](const u32 (&x)[16], int j0) {
@@ -599,7 +601,8 @@ __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ 
       o[3][g] = __builtin_amdgcn_perm(d, b, 0x07060302u);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[(size_t)(j0 + j) * 4 * 64] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    for (int j = 0; j < 4; ++j)
+      if (j0 + j < nplanes) out[(size_t)(j0 + j) * 4 * 64] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
   };
   planes(lo, 0);
   planes(hi, 4);
@@ -686,6 +689,7 @@ struct PwItems {
   int MTm;       // filter blocks of F per column tile
   int F_log;     // 7, 6 or 5
   int s_log;     // 0, 1 or 2
+  int skip7;     // bit l: modulus l is below 2^54, so the eighth column digit is 0 throughout and its products are left out
 };
 static PwItems pw_items(int n_live, int M, int n_cu) {
   PwItems it;
@@ -697,6 +701,7 @@ static PwItems pw_items(int n_live, int M, int n_cu) {
   it.s_log = 0;
   while (it.s_log < 2 && it.F_log - (it.s_log + 1) >= 5 && (rem << (it.s_log + 1)) <= n_cu) ++it.s_log;
   it.n_items = it.n_main + (rem << it.s_log);
+  it.skip7 = 0;
   return it;
 }
 
@@ -789,6 +794,7 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
     const int u0 = __builtin_amdgcn_readfirstlane(((fb & 127) >> 4) + wm * msn);   // ... its unit in the 128-filter block
     // tiles of this wave that hold a filter at all (wave-uniform; fewer only in the layer's last block)
     const int ms_used = __builtin_amdgcn_readfirstlane(min(msn, max(0, (M - wfb + 15) / 16)));
+    const int nj = (items.skip7 >> (((size_t)tile * 64 >> logN) & 1)) & 1 ? 7 : 8;   // column digits with products
     v4i sum[4][10];
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms)
@@ -826,7 +832,8 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
             const v4i av = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              sum[ms][a + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], sum[ms][a + j], 0, 0, 0);
+              if (j < 7 || nj == 8)
+                sum[ms][a + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], sum[ms][a + j], 0, 0, 0);
           }
         }
       }
@@ -954,11 +961,13 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
       return MMH_ERR_MEMORY;
     }
     if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
+    const int skip7 = ((ctx->q[0] >> 54) == 0 ? 1 : 0) | ((ctx->q[1] >> 54) == 0 ? 2 : 0);
     hipLaunchKernelGGL(pw_expand_kernel, dim3((unsigned)n_live, (unsigned)KC), dim3(256), 0, s, image, p->d_pw_chan,
                        p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter,
-                       fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0});
+                       fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0}, skip7);
     if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
-    const PwItems items = pw_items(n_live, z.M, ctx->n_cu);
+    PwItems items = pw_items(n_live, z.M, ctx->n_cu);
+    items.skip7 = skip7;
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_live, S, ctx->logN,
                        ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items);
