@@ -31,13 +31,54 @@ PMC_FILE = "profiles/r02_ntt_pmc.json"
 def pmc_traffic(ntts_per_launch):
     """HBM bytes per launch of ntt_fwd_kernel<12>: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of
     MI355X_MICROARCH.md) from separate rocprofv3 --pmc passes over the same kernel (tools/evidence.sh ->
-    profiles/r02_ntt_pmc.json, collected on 8192 limb-NTTs per launch), scaled to this launch.  PMC passes cannot run
-    inside this process, so the figure is the RECORDED one; `traffic_source` in the line names the file."""
+    profiles/r02_ntt_pmc.json, collected on 8192 limb-NTTs per launch), scaled to this launch: the RECORDED figure,
+    used when measured_traffic() below cannot run; `traffic_source` in the line says which of the two it is."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             return json.load(f)["traffic_bytes"] * ntts_per_launch / 8192
     except (OSError, KeyError, ValueError):
         return None
+
+
+def measured_traffic(ntts_per_launch, limit_s=60):
+    """The same figure measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE: the
+    guide's separate passes) over tools/ntt_bench, which launches ntt_fwd_kernel<12> on 8192 limb-NTTs through the
+    same library; 2 x FETCH_SIZE + WRITE_SIZE (KiB), scaled to this launch.  None when the profiler or the binary is
+    missing, a pass fails or overruns its limit, or this process itself runs under a profiler.  Called before this
+    process initialises the GPU (main): the passes are over by the time it does."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe, prof = os.path.join(ROOT, "tools", "ntt_bench"), shutil.which("rocprofv3")
+    if not (prof and os.access(exe, os.X_OK)) or any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp",
+               LD_LIBRARY_PATH=os.path.join(ROOT, "openmm_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    avg = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            child = subprocess.Popen([prof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--",
+                                      exe, "12", "4096", "5"], cwd=tmp, env=env, stdout=subprocess.DEVNULL,
+                                     stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                if child.wait(timeout=limit_s) != 0:
+                    return None
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)   # the group this call started, nothing else
+                child.wait()
+                return None
+            vals = [float(row["Counter_Value"])
+                    for f in glob.glob(f"{out}/**/*_counter_collection.csv", recursive=True)
+                    for row in csv.DictReader(open(f))
+                    if "ntt_fwd_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not vals:
+                return None
+            avg[counter] = sum(vals) / len(vals)
+    return (2 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024 * ntts_per_launch / 8192
 
 
 def cpu_baseline(seconds=12.0):
@@ -498,6 +539,13 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python bench.py --gpus N starts them itself)")
 
+    # The PMC passes come first, as child processes that have ended before this process touches the GPU at all
+    # (nothing is started from a process that holds a GPU context).  The profiled runs (--no-cpu, --headline-only)
+    # and multi-rank runs keep the recorded figure.
+    live_traffic = None
+    if world == 1 and not args.no_cpu and not args.headline_only:
+        live_traffic = measured_traffic(args.polys * 2)
+
     import torch
     import torch.distributed as dist
     import openmm_amd
@@ -559,6 +607,12 @@ def main():
                 torch.cuda.synchronize()
                 extra.update(host_to_host_leg())
     if rank == 0:
+        traffic = live_traffic
+        source = ("measured at the start of this run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/ntt_bench, "
+                  "8192 limb-NTTs per launch, scaled to this launch")
+        if traffic is None:
+            traffic = pmc_traffic(ntts_per_step)
+            source = f"recorded, not measured in this run: {PMC_FILE} (tools/evidence.sh, round 2)"
         line = {
             "metric": "64-bit NTTs/sec (N=4096/8192) + ResNet50 HE-linear ms at 1/2/4/8 GPUs",
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
@@ -570,8 +624,7 @@ def main():
                        "polys_per_gpu": args.polys, "limbs": 2, "ntts_per_step_per_gpu": ntts_per_step,
                        "parallelism": f"independent batches x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(ntts_per_step),
-                         "traffic_source": f"recorded, not measured in this run: {PMC_FILE} (tools/evidence.sh, round 2)",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
                          "kernel": "ntt_fwd_kernel<12>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ntts_per_step * BYTES_PER_NTT[4096],
                          "int64_valu": {"achieved": ntts_per_step * BUTTERFLIES[4096] * MADS_PER_BUTTERFLY
