@@ -295,11 +295,13 @@ __device__ __forceinline__ u32 pw_weights_body(size_t gid, const PwWeightArgs &a
     dig[0][j >> 2] |= (u32)((wb & 0xff) ^ 0x80) << sh;
     dig[1][j >> 2] |= (u32)(((wb >> 8) & 0xff) ^ 0x80) << sh;
     dig[2][j >> 2] |= (u32)(d2 & 0xff) << sh;
-    if (m < Mpad && ch < Cpad) {
+    if (m < Mpad && ch < Cpad) {   // (a call that multiplies on the matrix cores leaves both forms out: wp, wl null)
       const size_t idx = (size_t)ch * Mpad + m;
-      a.wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
-      a.wl[idx] = neg ? v + (a.q0 - t.q) : v;                            // fast plain lift, limb 0
-      a.wl[(size_t)Cpad * Mpad + idx] = neg ? v + (a.q1 - t.q) : v;      // limb 1
+      if (a.wp) a.wp[idx] = (u32)((u64(1) << kPwBiasLog) + (neg ? 0 - mag : mag));
+      if (a.wl) {
+        a.wl[idx] = neg ? v + (a.q0 - t.q) : v;                            // fast plain lift, limb 0
+        a.wl[(size_t)Cpad * Mpad + idx] = neg ? v + (a.q1 - t.q) : v;      // limb 1
+      }
     }
   }
   const int kc = kg >> 2;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
       }
     };
     const int n_chunks = Cpad / kPwChunk;
-    const u64 *__restrict__ wg = wl + (size_t)l * Cpad * Mpad + mbase;
+    const u64 *__restrict__ wg = wl ? wl + (size_t)l * Cpad * Mpad + mbase : nullptr;
     u64 x0[TM], x1[TM], B0 = 0, B1 = 0;  // fast: the two 30-bit partial sums; general: 128-bit lo/hi
 #pragma unroll
     for (int j = 0; j < TM; ++j) x0[j] = x1[j] = 0;
@@ -636,10 +638,16 @@ __device__ __forceinline__ void fold_words(u32 &w0, u32 &w1, u32 &w2, u32 w3, u3
 // 64-bit weights, exactly as pw_gemm_kernel<false> does (lazy 128-bit sums reduced every 8 taps, canonical results).
 // A branch here instead of a second launch that nearly always exits at once (4-5 us per layer).  Not tuned: wave w
 // takes filters 16 w .. 16 w + 15, every lane one column, the rotated column value re-read per tap.
+struct PwLift {   // where the lifted weights come from when no wl array was written: the raw filter tensor [M][C]
+  const u64 *raw;
+  int C;
+  ModC t;
+  u64 thr;
+};
 __device__ __noinline__ void pw_general_tile(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
                                              const u64 *__restrict__ wl, u64 *__restrict__ acc, int M, int Mpad,
                                              int Cpad, size_t S, int logN, const DevMod *__restrict__ mods, size_t c0,
-                                             int mt) {
+                                             int mt, const PwLift &lift) {
   const int N = 1 << logN, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t cols = S * 4 * N, col = c0 + lane;
   const int i = (int)(col & (N - 1)), pl = (int)((c0 >> logN) & 3), l = pl & 1;
@@ -658,10 +666,16 @@ __device__ __noinline__ void pw_general_tile(const u64 *__restrict__ image, cons
     const PwChannel pc = chan[k];
     const u64 v = base[(size_t)pc.row * row_step + ((i - pc.e) & (N - 1))];
     const u64 u = i < pc.e ? (v ? q.q - v : 0) : v;   // X^N = -1
-    const u64 *__restrict__ wr = wg + (size_t)k * Mpad;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const u64 wj = j < nf ? wr[j] : 0, p = u * wj;
+      u64 wj = 0;
+      if (wl) {
+        wj = j < nf ? wg[(size_t)k * Mpad + j] : 0;
+      } else if (mbase + j < M && k < lift.C) {   // multiply_plain's fast lift of the weight, as pw_weights_body writes it
+        const u64 v = red_t(lift.raw[(size_t)(mbase + j) * lift.C + k], lift.t);
+        wj = v >= lift.thr ? v + (q.q - lift.t.q) : v;
+      }
+      const u64 p = u * wj;
       x0[j] += p;
       x1[j] += mulhi64(u, wj) + (x0[j] < p);
     }
@@ -711,14 +725,14 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
                                                       u64 *__restrict__ acc, int M, int KC, int n_live, size_t S,
                                                       int logN, const DevMod *__restrict__ mods,
                                                       const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
-                                                      const u64 *__restrict__ wl, int Mpad, int Cpad, PwItems items) {
+                                                      const u64 *__restrict__ wl, int Mpad, int Cpad, PwItems items, PwLift lift) {
   extern __shared__ uint4 pw_lds[];
   const u32 fl = *flag;
   const int G = (int)gridDim.x;
   if (fl & 1u) {                        // weights of 2^20 and more: the lifted form (rare), 128 filters per item
     const int MT = (M + 127) >> 7;
     for (int idx = blockIdx.x; idx < n_live * MT; idx += G)
-      pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)live[idx / MT] * 64, idx % MT);
+      pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)live[idx / MT] * 64, idx % MT, lift);
     return;
   }
   const int nA = (fl & 2u) ? 3 : 2;
@@ -939,7 +953,7 @@ static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, c
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
                              const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1,
                              const u32 *nzmap = nullptr, u32 *zero_filter = nullptr, const PwFold *fold = nullptr,
-                             void *verdict_event = nullptr) {
+                             void *verdict_event = nullptr, const u64 *raw_filters = nullptr) {
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   const PwSizes z = pw_sizes(p);
@@ -970,7 +984,8 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     items.skip7 = skip7;
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_live, S, ctx->logN,
-                       ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items);
+                       ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items,
+                       PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr});
     (void)scratch_free(u8, s);
   }
   // (on the matrix-core path the product kernel carries the lifted-weight form as a branch of its own)
@@ -1330,8 +1345,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     const PwSizes z = pw_sizes(p);
     const unsigned n_img = nblk(p->n_in << ctx->logN), n_w = prepared ? 0 : nblk((size_t)(z.Cpad64 / 16) * z.Mpad128);
     if (!prepared) {
-      grab(&wp, (size_t)z.Cpad * z.Mpad * 4);
-      grab(&wl, (size_t)z.Cpad * z.Mpad * 16);
+      // byte digits only: the biased 32-bit form belongs to the vector-ALU kernels, and the rare lifted-weight branch
+      // of the product kernel lifts from the raw tensor itself (20 of 23 bytes per weight not written)
       grab(&w8, z.w8_bytes());
       grab(&flag_word, 4 * (size_t)(1 + n_w));              // the folded word, then one word per weights workgroup
     }
@@ -1400,7 +1415,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && front && !prepared)
     rc = pointwise_product(p, (const u64 *)image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8,
                            (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold,
-                           nz_inline ? verdict_event : nullptr);
+                           nz_inline ? verdict_event : nullptr, d_filters_raw);
   if (!rc && direct && !prepared && !front)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
   if (!rc && !direct && !prepared && d_filters_raw)
