@@ -632,7 +632,8 @@ __device__ __forceinline__ void fold_words(u32 &w0, u32 &w1, u32 &w2, u32 w3, u3
 // within 3 % of the plain order: the digit image sits in the Infinity Cache either way.)
 // Where the time goes, 256 -> 256 3x3 at 14x14 (36 steps, 88 us): with the copies switched off 73 us, with the
 // products switched off 54 us (48 KiB per step and compute unit = 10 TB/s over the chip), with both 8 us; one step
-// takes 2.0 us against 0.85 us of matrix-core issue at the nominal clock.
+// takes 2.0 us = 3,700 cycles at the 2.03-2.11 GHz the kernel holds, against ~3,400 for its 120 products at the
+// rate v_mfma_i32_16x16x64_i8 sustains back to back (tools/mfma_i8_probe.hip; 1,920 by the nominal 16 cycles).
 // The rare form inside the product kernel: some weight of the layer is 2^20 or more in magnitude, so the byte-digit
 // product does not apply and the workgroup computes its 128 filters x 64 columns on the vector ALU from the lifted
 // 64-bit weights, exactly as pw_gemm_kernel<false> does (lazy 128-bit sums reduced every 8 taps, canonical results).
