@@ -237,7 +237,6 @@ int launch_gather_targets(const mmh_ctx *ctx, const u64 *pts, u64 *out, size_t g
 // Everything is exact mod q_l, so the kept coefficients equal the per-term multiply_plain schedule bit
 // for bit.  Cheaper than the transform route while wc is small (per output column C scalar MACs against
 // Cs * (2 NTTs + 4 dyadic MACs)); measured break-even near 28 channels per polynomial.
-constexpr int kPwMaxWc = 160;  // break-even against the transform route
 constexpr int kPwBiasLog = 20;  // fast form: weights in (-2^20, 2^20) stored as w + 2^20
 
 // weights [M][K] (mod t; K = C*fh*fw taps) -> biased 32-bit form wp[Cpad][Mpad], lifted 64-bit form
