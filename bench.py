@@ -135,6 +135,15 @@ def cpu_homconv_ms(reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, threads
 
 
+def prewarm(fn, torch, seconds=0.05):
+    """fn repeated untimed for `seconds` (see timed(): an idle chip takes tens of ms of load to settle)"""
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+
+
 def conversion_leg(torch, openmm_amd):
     """ring_to_field local share arithmetic on 10^7 elements (tests/ring_to_field_test.cpp:171), l=32,
     p=4293918721, ALICE's side: the pre kernel (in -> tmp, msb, corr) and the post kernel (tmp, msb, y -> out)
@@ -154,7 +163,7 @@ def conversion_leg(torch, openmm_amd):
         L.check(lib.mmh_r2f_post(1, L.dptr(tmp), L.dptr(msb), L.dptr(y), n, l, p, L.dptr(out), s))
 
     both()
-    torch.cuda.synchronize()
+    prewarm(both, torch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
@@ -172,7 +181,7 @@ def conversion_leg(torch, openmm_amd):
         L.check(lib.mmh_trunc_post(1, L.dptr(adj), L.dptr(aw), n, 12, l, 1, 0, L.dptr(out), s))
 
     trunc()
-    torch.cuda.synchronize()
+    prewarm(trunc, torch)
     e0.record()
     for _ in range(20):
         trunc()
@@ -198,7 +207,7 @@ def conversion_leg(torch, openmm_amd):
             L.check(lib.mmh_cot_recv(L.dptr(rcm), L.dptr(choice), seed, 0, L.dptr(wire), n, l, p, prime, L.dptr(out),
                                      s))
         cot()
-        torch.cuda.synchronize()
+        prewarm(cot, torch)
         e0.record()
         for _ in range(10):
             cot()
@@ -217,7 +226,7 @@ def conversion_leg(torch, openmm_amd):
         L.check(lib.mmh_cot_send(L.dptr(rcm), delta, seed, 0, L.dptr(corr), n, l, p, 1, L.dptr(y0), L.dptr(wire), s))
         L.check(lib.mmh_r2f_post(1, L.dptr(tmp), L.dptr(msb), L.dptr(y0), n, l, p, L.dptr(out), s))
     chain()
-    torch.cuda.synchronize()
+    prewarm(chain, torch)
     e0.record()
     for _ in range(10):
         chain()
@@ -238,9 +247,9 @@ def layer_legs(torch, openmm_amd, local):
     gen = torch.Generator(device="cuda").manual_seed(0x4D264D)
     rnd = lambda lo, hi, *shape: torch.randint(lo, hi, shape, dtype=torch.int64, device="cuda", generator=gen)
 
-    def ms(fn, reps=10):
+    def ms(fn, reps=20):
         fn()
-        torch.cuda.synchronize()
+        prewarm(fn, torch, 0.03)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
