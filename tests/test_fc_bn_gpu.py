@@ -107,6 +107,17 @@ def test_fc_rejects_zero_block(mm):
     assert ei.value.code == 7  # ERR_INVALID_ARG, hom_fc_ss.cc:419
 
 
+def test_fc_and_bole_bit_exact_n8192(mm, monkeypatch):
+    """the FC and BOLE / bn flows on N = 8192 contexts (the reference's are N = 4096, cheetah-api.cpp:101,152; the entry
+    points take either): the LOGN = 13 kernels and the batching tables of the larger ring against the oracle"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "N", 8192)
+    test_fc_layer_bit_exact(mm, 70, 300, True)
+    test_fc_layer_bit_exact(mm, 5, 9000, False)
+    test_bole_bn_bit_exact(mm, 100)
+    test_bole_bn_bit_exact(mm, 20000)
+
+
 @pytest.mark.parametrize("n", [1, 100, 4096, 10000, 1 << 20])   # 2^20: tests/bole_test.cpp:568, BASELINE configs[0,2]
 def test_bole_bn_bit_exact(mm, n):
     from openmm_amd.hom_bn_ss import HomBNSS, Meta
