@@ -107,6 +107,18 @@ def test_conv_layer_bit_exact_n8192(mm, monkeypatch, ishape, fhw, M, same, strid
     test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, shared, route)
 
 
+@pytest.mark.parametrize("route", ["0", "1"])
+@pytest.mark.parametrize("ring_bits", [32, 41, 44])
+def test_conv_layer_bit_exact_other_rings(mm, monkeypatch, ring_bits, route):
+    """the ring sizes of the other shipped networks (bitlength 32 for SqueezeNet / DenseNet121, 41 in
+    sci::default_prime_mod's table, 44 the largest CheetahLinear accepts): the tail's masks, truncation widths and
+    scale-and-round constants all depend on t"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "T", 1 << ring_bits)
+    test_conv_layer_bit_exact(mm, monkeypatch, (9, 20, 20), (3, 3), 5, 1, 1, True, route)
+    test_conv_layer_bit_exact(mm, monkeypatch, (40, 14, 14), (1, 1), 70, 0, 2, True, route)
+
+
 @pytest.mark.parametrize("route", ["model", "0", "1"])
 @pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", CASES)
 def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, shared, route):
@@ -191,7 +203,7 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
     assert np.array_equal(host(client.unpackResult(packed, meta)), ref_out)
     kept = int(plan_kept(cv, ref_out))
     assert packed.shape[1] < 2 * N
-    if N == 4096:   # (the widths of the reference's configuration: 51 bits of c1, 39 of a kept coefficient of c0)
+    if N == 4096 and T == 1 << 37:   # (the widths of BASELINE's configuration: 51 bits of c1, 39 of a kept coefficient of c0)
         assert packed.shape[1] <= (N * 51 + 63) // 64 + (kept * 39 + 63) // 64
     ideal = ideal_conv(img, filters, same, stride, T)
     diff = (got_dec.astype(object) + host(got_share).astype(object) - ideal) % T
