@@ -107,6 +107,17 @@ def test_fc_rejects_zero_block(mm):
     assert ei.value.code == 7  # ERR_INVALID_ARG, hom_fc_ss.cc:419
 
 
+@pytest.mark.parametrize("ring_bits,prime", [(32, 4293918721), (41, 2198100901889), (37, 137438822401)])
+def test_fc_and_bole_bit_exact_other_moduli(mm, monkeypatch, ring_bits, prime):
+    """the other rings and their fields of sci::default_prime_mod (SCI/src/utils/constants.h:45-50; BASELINE runs 37 for
+    the FC and the 32-bit prime for BOLE): the tails' constants depend on t, the batching tables on p"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "T", 1 << ring_bits)
+    monkeypatch.setattr(sys.modules[__name__], "P32", prime)
+    test_fc_layer_bit_exact(mm, 70, 300, True)
+    test_bole_bn_bit_exact(mm, 10000)
+
+
 def test_fc_and_bole_bit_exact_n8192(mm, monkeypatch):
     """the FC and BOLE / bn flows on N = 8192 contexts (the reference's are N = 4096, cheetah-api.cpp:101,152; the entry
     points take either): the LOGN = 13 kernels and the batching tables of the larger ring against the oracle"""
