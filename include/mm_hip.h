@@ -279,6 +279,21 @@ int mmh_conv_plan_destroy(mmh_conv_plan *plan);
 int mmh_conv_plan_info(const mmh_conv_plan *plan, size_t *n_in_cts, size_t *n_channel_slices,
                        size_t *n_spatial_slices, size_t *n_out_cts, int64_t out_shape[3],
                        int64_t slice_strides[3]);
+/* What one server call of the plan's layer does, for a caller that prices it against the machine (bench.py's
+ * roofline of the network legs): the route the plan's cost model picked (1 = direct product of the rotated input
+ * columns with the weight matrix on the matrix cores, 0 = transform route) for filters that arrive with the call and
+ * for prepared ones, the taps K = C*fh*fw of a filter and K rounded up to the product kernel's 64-tap step, the
+ * coefficient columns the direct product computes per limb (all of c1, of c0 the 64-column tiles that hold a
+ * coefficient removeUnusedCoeffs keeps; 0 when the plan cannot take the direct route), and the counts of
+ * mmh_conv_plan_info.  No counterpart in the reference (its schedule is fixed: conv2DOneFilter). */
+typedef struct mmh_conv_work {
+  int32_t direct_fresh, direct_prepared;
+  int64_t taps, taps_padded;
+  int64_t live_columns[2];
+  int64_t n_in, n_out, n_cslices, n_spatial, n_targets;
+  int64_t limbs, poly_degree;
+} mmh_conv_work;
+int mmh_conv_plan_work(const mmh_conv_plan *plan, mmh_conv_work *work);
 /* TensorEncoder::EncodeImageShare (tensor_encoder.cc:178-244): image -> n_in plaintexts [n_in][N] */
 int mmh_conv_encode_image(const mmh_conv_plan *plan, const uint64_t *d_img, uint64_t *d_pts, void *stream);
 /* HomConv2DSS::encodeFilters -> TensorEncoder::EncodeFilter (hom_conv2d_ss.cc:537-561,

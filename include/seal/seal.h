@@ -13,8 +13,9 @@
 //
 // What is not SEAL: randomness comes from the device ChaCha20 sampler (seeded from the OS or from the caller's
 // UniformRandomGenerator), so streams differ from SEAL's Blake2xb ones; save/load write SEAL 3.7's framing with
-// compr_mode none (seal/wire.h: header, members, seeded form, BLAKE2b parms_id; parity unpinned) and refuse a
-// zstd-compressed stream, which an unmodified SEAL writes by default.  Only BFV, n_special_primes = 0, N in {4096, 8192},
+// compr_mode none (seal/wire.h: header, members, seeded form, BLAKE2b parms_id; parity unpinned) and inflate a
+// zstd-compressed stream, which an unmodified SEAL writes by default, with the decoder of seal/zstd_decode.h (zlib
+// streams are refused).  Only BFV, n_special_primes = 0, N in {4096, 8192},
 // at most two coefficient moduli -- what cheetah-api.cpp:95-105,:151-162 sets up.
 #pragma once
 #include <algorithm>

@@ -283,7 +283,8 @@ struct Reader {
     (void)u16();
     const std::uint64_t total = u64();
     if (magic != kMagic || hsize != 0x10) throw std::logic_error("seal wire: not a SEAL object (bad header)");
-    if (vmaj != 3 || (vmin != 6 && vmin != 7)) throw std::logic_error("seal wire: SEAL version other than 3.6 / 3.7");
+    // 3.7 only: load_ciphertext reads 3.7's member list (with correction_factor), which a 3.6 object does not have
+    if (vmaj != 3 || vmin != 7) throw std::logic_error("seal wire: SEAL version other than 3.7");
     if (compr == compr_zlib)
       throw std::logic_error("seal wire: compressed stream (compr_mode zlib): no zlib decoder in this build; the peer "
                              "must save with compr_mode_type::zstd or none");
@@ -296,6 +297,10 @@ struct Reader {
     return (std::size_t)total - kHeaderBytes;
   }
 };
+
+// The largest ciphertext object a context of this facade can hold (16 polynomials of N = 8192 with two moduli, plus
+// headers): what a peer-declared zstd content size may make the loader reserve before any metadata is validated.
+static constexpr std::size_t kMaxCtBytes = 16 * 8192 * 2 * 8 + 4096;
 
 struct CtMeta {
   std::array<std::uint64_t, 4> parms_id{};
@@ -333,7 +338,8 @@ inline std::string save_ciphertext(const CtMeta &m, const std::uint64_t *data, c
 // Ciphertext::load_members up to the data: fills `m`, returns the words present and sets seeded / seed.  `data`
 // receives size * N * L words; for a seeded object the second polynomial is left for the caller to expand.
 inline std::size_t load_ciphertext(const std::uint8_t *bytes, std::size_t n, CtMeta &m, std::vector<std::uint64_t> &data,
-                                   bool &seeded, std::uint8_t (&seed)[kSeedBytes], std::size_t *consumed = nullptr) {
+                                   bool &seeded, std::uint8_t (&seed)[kSeedBytes], std::size_t *consumed = nullptr,
+                                   std::size_t max_inflated = kMaxCtBytes) {
   Reader outer{bytes, bytes + n};
   std::uint8_t compr = compr_none;
   std::size_t body = outer.header(&compr);
@@ -344,7 +350,7 @@ inline std::size_t load_ciphertext(const std::uint8_t *bytes, std::size_t n, CtM
   Reader r{outer.p, outer.p + body};
   if (compr == compr_zstd) {
     try {
-      inflated = zstd::decompress(outer.p, body, (std::size_t)1 << 28);
+      inflated = zstd::decompress(outer.p, body, max_inflated);
     } catch (const zstd::Error &e) {
       throw std::logic_error(std::string("seal wire: ") + e.what());
     }

@@ -855,6 +855,7 @@ extern "C" int mmh_batch_decode_noalloc(const mmh_ctx *ctx, const uint64_t *d_pt
   int current = -1;
   MMH_HIP(hipGetDevice(&current));
   MMH_REQUIRE(current == ctx->device, MMH_ERR_CONFIG);  // the context's tables live on ctx->device
+  (void)hipGetLastError();  // a stale error another library left behind is not this call's (DeviceScope does the same)
   u64 *tmp = nullptr;
   CHECK_RC(decode_scratch_ptr(current, &tmp));
   hipStream_t s = (hipStream_t)stream;

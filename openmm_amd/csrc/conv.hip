@@ -70,6 +70,8 @@ struct mmh_conv_plan {
   mmh::PwChannel *d_pw_chan = nullptr;   // [C rounded up to 64]: input row (channel slice) and rotation of a channel
   int *d_pw_live = nullptr;              // [pw_live_tiles] the 64-column tiles the product computes (index = column / 64)
   size_t pw_live_tiles = 0;
+  size_t pw_live_tiles_limb[2] = {0, 0};  // of those, the tiles of limb 0 / limb 1 (mmh_conv_plan_work)
+  size_t pw_taps_padded = 0;             // taps rounded up to the product kernel's 64-tap step
   std::vector<void *> allocs;
 };
 
@@ -1168,9 +1170,10 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
       const size_t sp_i = (b * 64) / (4 * (size_t)N), pl = ((b * 64) / (size_t)N) & 3, i0 = (b * 64) % (size_t)N;
       bool live = pl >= 2;
       for (size_t i = 0; i < 64 && !live; ++i) live = keep[sp_i * N + i0 + i] != 0;
-      if (live) live_tiles.push_back((int)b);
+      if (live) live_tiles.push_back((int)b), ++p->pw_live_tiles_limb[pl & 1];
     }
     p->pw_live_tiles = live_tiles.size();
+    p->pw_taps_padded = chan.size();
     // the product's two LDS buffers exceed the static 64 KiB: opt in (per device; plans are made on the context's)
     if (hipFuncSetAttribute((const void *)pw_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) !=
         hipSuccess) {
@@ -1233,6 +1236,17 @@ extern "C" int mmh_conv_plan_info(const mmh_conv_plan *p, size_t *n_in_cts, size
   if (n_out_cts) *n_out_cts = p->n_out;
   if (out_shape) out_shape[0] = p->meta.n_filters, out_shape[1] = p->out_h, out_shape[2] = p->out_w;
   if (slice_strides) slice_strides[0] = p->split.win_c, slice_strides[1] = p->split.win_h, slice_strides[2] = p->split.win_w;
+  return MMH_OK;
+}
+
+extern "C" int mmh_conv_plan_work(const mmh_conv_plan *p, mmh_conv_work *w) {
+  MMH_REQUIRE(p && w, MMH_ERR_NULL_POINTER);
+  w->direct_fresh = p->direct_fresh, w->direct_prepared = p->direct_prepared;
+  w->taps = p->f.count(), w->taps_padded = (int64_t)p->pw_taps_padded;
+  w->live_columns[0] = 64 * (int64_t)p->pw_live_tiles_limb[0], w->live_columns[1] = 64 * (int64_t)p->pw_live_tiles_limb[1];
+  w->n_in = (int64_t)p->n_in, w->n_out = (int64_t)p->n_out, w->n_cslices = (int64_t)p->n_cslices;
+  w->n_spatial = (int64_t)p->n_spatial, w->n_targets = (int64_t)p->n_targets;
+  w->limbs = (int64_t)p->ctx->L, w->poly_degree = (int64_t)p->ctx->N;
   return MMH_OK;
 }
 

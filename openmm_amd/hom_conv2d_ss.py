@@ -31,6 +31,14 @@ class ConvMetaC(C.Structure):
                 ("stride", C.c_int32), ("is_shared_input", C.c_int32)]
 
 
+class ConvWorkC(C.Structure):
+    """mmh_conv_work (include/mm_hip.h)"""
+    _fields_ = [("direct_fresh", C.c_int32), ("direct_prepared", C.c_int32), ("taps", C.c_int64),
+                ("taps_padded", C.c_int64), ("live_columns", C.c_int64 * 2), ("n_in", C.c_int64), ("n_out", C.c_int64),
+                ("n_cslices", C.c_int64), ("n_spatial", C.c_int64), ("n_targets", C.c_int64), ("limbs", C.c_int64),
+                ("poly_degree", C.c_int64)]
+
+
 @dataclass
 class Meta:
     """HomConv2DSS::Meta (hom_conv2d_ss.h:31-38)"""
@@ -60,6 +68,12 @@ class Plan:
         self.n_in, self.n_cslices, self.n_spatial, self.n_out = a.value, b.value, c.value, d.value
         self.out_shape = tuple(int(x) for x in oshape)
         self.slice_strides = tuple(int(x) for x in strides)
+
+    def work(self):
+        """what one server call of this layer does (mmh_conv_plan_work): route, taps, live columns, counts"""
+        w = ConvWorkC()
+        L.check(self.ctx.lib.mmh_conv_plan_work(self.handle, C.byref(w)))
+        return w
 
     def __del__(self):
         try:

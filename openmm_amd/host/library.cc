@@ -58,11 +58,11 @@ void Library::MatMul2D(int32_t d0, int32_t d1, int32_t d2, const intType *mat_A,
 void Library::Conv2DWrapper(signedIntType N, signedIntType H, signedIntType W, signedIntType CI, signedIntType FH,
                             signedIntType FW, signedIntType CO, signedIntType zPadHLeft, signedIntType zPadHRight,
                             signedIntType zPadWLeft, signedIntType zPadWRight, signedIntType strideH,
-                            signedIntType /*strideW*/, intType *inputArr, intType *filterArr, intType *outArr) const {
+                            signedIntType strideW, intType *inputArr, intType *filterArr, intType *outArr) const {
   if (zPadWLeft < zPadWRight) std::swap(zPadWLeft, zPadWRight);
   if (zPadHLeft < zPadHRight) std::swap(zPadHLeft, zPadHRight);
   const signedIntType newH = (H + zPadHLeft + zPadHRight - FH) / strideH + 1;
-  const signedIntType newW = (W + zPadWLeft + zPadWRight - FW) / strideH + 1;
+  const signedIntType newW = (W + zPadWLeft + zPadWRight - FW) / strideW + 1;  // :237 (meta.stride is strideH alone, :262)
   CheetahLinear::ConvMeta meta;
   meta.ishape = TensorShape({CI, H, W});
   meta.fshape = TensorShape({CI, FH, FW});

@@ -26,6 +26,7 @@ _vp, _sz, _u64, _int = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
 # name -> argtypes; every function returns int (gemini::Code) unless listed in _RESTYPE
 SIGNATURES = {
     "mmh_device_count": [C.POINTER(_int)],
+    "mmh_conv_plan_work": [_vp, _vp],
     "mmh_ctx_create": [C.POINTER(_vp), _sz, C.POINTER(_u64), _sz, _u64, _int],
     "mmh_ctx_create_bits": [C.POINTER(_vp), _sz, C.POINTER(_int), _sz, _u64, _int],
     "mmh_ctx_destroy": [_vp],

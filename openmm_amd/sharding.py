@@ -8,8 +8,8 @@ BN/BOLE (hom_bn_ss.cc:261-271, :302-309), element ranges of the conversions
 replicated inputs with no data-path collective; the only exchange is the reassembly of the per-rank
 results on the rank that serialises them for the network, in one of two ways:
 
-* ``gather``: one RCCL gather straight into a pre-sized buffer on rank 0 (the ranks compute into buffers of
-  the common shard size, so nothing is padded, listed or concatenated afterwards);
+* ``gather``: ONE RCCL gather per layer straight into a pre-sized buffer on rank 0 (every rank computes into one
+  flat block [ciphertexts | share] of the common shard size, so nothing is padded, listed or concatenated afterwards);
 * ``d2h``: no collective at all: every rank copies its slice device-to-host, asynchronously, to its offset
   in one page-locked host buffer that all ranks map (the serialiser reads from host memory anyway).
 """
@@ -127,48 +127,83 @@ class ShardedConv:
         self._host = None
 
     def _buffers(self, like, n_sp, out_shape, ct_tail):
-        """per-rank result buffers of the common shard size, the pre-sized assembly buffers on rank 0 (gather) or
-        the shared host buffer (d2h); made once per layer object"""
+        """One flat per-rank result block [ciphertexts | share] of the common shard size, so that ONE collective (or one
+        host copy) moves both; on rank 0 the assembly block [world][ciphertexts | share] (gather) or the shared host
+        buffer (d2h).  Made once per layer object.  Returns (block, cts view, share view, assembly)."""
         if self._bufs is None:
-            mk = lambda *s: torch.zeros(s, dtype=like.dtype, device=like.device)
-            cts, share = mk(self.per * n_sp, *ct_tail), mk(self.per, *out_shape[1:])
-            all_cts = all_share = None
+            n_c = self.per * n_sp * int(torch.Size(ct_tail).numel())
+            n_s = self.per * int(torch.Size(out_shape[1:]).numel())
+            block = torch.zeros(n_c + n_s, dtype=like.dtype, device=like.device)
+            cts = block[:n_c].view(self.per * n_sp, *ct_tail)
+            share = block[n_c:].view(self.per, *out_shape[1:])
+            assembly = None
             if self.mode == "gather" and self.rank == 0:
-                all_cts, all_share = mk(self.world * self.per * n_sp, *ct_tail), mk(self.world * self.per, *out_shape[1:])
+                assembly = torch.zeros(self.world, n_c + n_s, dtype=like.dtype, device=like.device)
             if self.mode == "d2h" and self.world > 1:
-                self._host = SharedPinned(self.world * (cts.numel() + share.numel()), self.group)
-            self._bufs = (cts, share, all_cts, all_share)
+                self._host = SharedPinned(self.world * (n_c + n_s), self.group)
+            self._bufs = (block, cts, share, assembly)
         return self._bufs
+
+    def _agree(self, err):
+        """Every rank learns whether ANY rank failed before the exchange, and all raise: a rank that raised alone
+        (e.g. the reference's error for an all-zero filter in its slice, conv2DOneFilter :573-580) would leave the
+        others waiting in the collective until its time-out."""
+        if self.world == 1:
+            if err is not None:
+                raise err
+            return
+        dev = "cpu" if dist.get_backend(self.group) == "gloo" or not torch.cuda.is_available() else "cuda"
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if err is not None:
+            raise err
+        if int(flag.item()):
+            raise RuntimeError("ShardedConv: another rank's filter slice failed (its error is raised there)")
 
     def run(self, img_share0, share_tensor, filters, rand_for):
         """img_share0: the client's ciphertexts (replicated); share_tensor: the server's share [C,H,W] (None when
         the input is not shared); filters [M,C,fh,fw] (this rank reads filters[lo:hi]); rand_for(n_out_local)
         supplies (u, e1, mask).  Returns (out_cts, out_share) on rank 0 -- device tensors in mode "gather", views of
-        the shared host buffer in mode "d2h" -- and (None, None) elsewhere."""
+        the shared host buffer in mode "d2h" -- and (None, None) elsewhere.  An error on any rank is raised on every
+        rank, before the exchange.  In mode "d2h" the views rank 0 gets stay valid until rank 0 enters its next run()
+        (the call begins with a barrier, so no rank overwrites the host buffer before that)."""
         n_local = self.hi - self.lo
         full = self.server.plan(self.meta)
         n_sp, N = full.n_spatial, img_share0.shape[-1]
-        cts, share, all_cts, all_share = self._buffers(img_share0, n_sp, full.out_shape, (2, 1, N))
+        block, cts, share, assembly = self._buffers(img_share0, n_sp, full.out_shape, (2, 1, N))
+        if self.mode == "d2h" and self.world > 1:
+            dist.barrier(self.group)   # rank 0 has consumed the previous result by the time it gets here
+        err = None
         if n_local > 0:   # more ranks than filters leaves trailing ranks idle: they contribute their (zero) buffers
-            self.server.conv2DSSFromTensors(img_share0, share_tensor, filters[self.lo:self.hi].contiguous(),
-                                            self.local_meta, rand_for(n_local * n_sp),
-                                            out=(cts[:n_local * n_sp], share[:n_local]))
+            try:
+                self.server.conv2DSSFromTensors(img_share0, share_tensor, filters[self.lo:self.hi].contiguous(),
+                                                self.local_meta, rand_for(n_local * n_sp),
+                                                out=(cts[:n_local * n_sp], share[:n_local]))
+            except Exception as e:   # agreed on below
+                err = e
+        self._agree(err)
         M = self.meta.n_filters
         if self.world == 1:
             return cts[:M * n_sp], share[:M]
-        if self.mode == "gather":
-            gather_into(cts, all_cts, 0, self.group)
-            gather_into(share, all_share, 0, self.group)
-            return (all_cts[:M * n_sp], all_share[:M]) if self.rank == 0 else (None, None)
-        host = self._host.t
         n_c, n_s = cts.numel(), share.numel()
+
+        if self.mode == "gather":
+            gather_into(block, None if assembly is None else assembly.view(-1), 0, self.group)   # ONE collective
+            if self.rank != 0:
+                return None, None
+            # rank r's block is [ciphertexts | share]: the two parts of all ranks are brought together here (one small
+            # device copy each on rank 0; the collective is what costs)
+            c = assembly[:, :n_c].reshape(self.world * self.per * n_sp, 2, 1, N)
+            sh = assembly[:, n_c:].reshape(self.world * self.per, *share.shape[1:])
+            return c[:M * n_sp], sh[:M]
+        host = self._host.t
         h_cts = host[:self.world * n_c].view(self.world * self.per * n_sp, 2, 1, N)
         h_share = host[self.world * n_c:self.world * (n_c + n_s)].view(self.world * self.per, *share.shape[1:])
         h_cts[self.rank * self.per * n_sp:(self.rank + 1) * self.per * n_sp].copy_(cts, non_blocking=True)
         h_share[self.rank * self.per:(self.rank + 1) * self.per].copy_(share, non_blocking=True)
-        if cts.is_cuda:
+        if block.is_cuda:
             torch.cuda.current_stream().synchronize()
-        dist.barrier(self.group)       # the only synchronisation: every slice has landed
+        dist.barrier(self.group)       # every slice has landed
         return (h_cts[:M * n_sp], h_share[:M]) if self.rank == 0 else (None, None)
 
 

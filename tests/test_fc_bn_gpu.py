@@ -220,6 +220,92 @@ def test_bn_vector_steps_fused_with_conversions(mm, n, party):
         h.decryptToVectorForRing(dev(out_ct), meta, 3)
 
 
+@pytest.mark.parametrize("n", [7 * 7 * 2048, 56 * 56 * 256])
+def test_network_bn_layer_bit_exact(mm, n):
+    """One live FusedBatchNorm4411 of ResNet50 (networks/main_resnet50.cpp:1060-1093 -> ElemWiseActModelVectorMult,
+    library_fixed_uniform_cheetah.cpp:567-600) at the network's own sizes -- 56*56*256 = 802,816 elements = 196
+    ciphertexts is the largest of its 18 -- with the shipped ring and field (ell = 37, p = 137438822401, k = 12):
+    Ring2Field -> CheetahLinear::bn -> Field2Ring_with_Truncate, both parties, every device step bit for bit against
+    the oracle (the conversions' post / pre steps through the entry points fused with the vector steps), the COT by
+    the oracle's ideal functionality, and the result within one unit of floor(x * scale / 2^k)
+    (tests/bole_test.cpp:286-289)."""
+    import torch
+    from openmm_amd.hom_bn_ss import HomBNSS, Meta
+    from tests.oracle_binding import A, load
+    ol = load()
+    bw, p, k = 37, 137438822401, 12
+    o, g = OracleCtx(N, (60, 49), p), mm.Context(N, (60, 49), p)
+    bn = BnOracle(o, n)
+    meta = Meta((n,), p, True)
+    sk, _ = keypair(o)
+    client, server = HomBNSS(), HomBNSS()
+    client.setUp_Field(p, g, sk_ntt=dev(sk))
+    server.setUp_Field(p, g)
+    ring = np.uint64((1 << bw) - 1)
+    # activations at scale k with |x| < 2^20, BN scales |s| < 2^13 (fixed point, scale k): |x s| < 2^33 < p / 4
+    x = (splitmix64(SEED + 40, n) % np.uint64(1 << 21)).astype(np.int64) - (1 << 20)
+    sc = (splitmix64(SEED + 41, n) % np.uint64(1 << 14)).astype(np.int64) - (1 << 13)
+    xa = splitmix64(SEED + 42, n) & ring
+    xb = (x.astype(np.uint64) - xa) & ring
+    scale_f = np.where(sc < 0, np.uint64(p) - (-sc).astype(np.uint64), sc.astype(np.uint64)).astype(np.uint64)  # getFieldElt
+    z = lambda dt=np.uint64: np.zeros(n, dt)
+
+    def ideal_cot(corr, choice, l, prime):   # SilentOT's functionality (silent_ot.h:85-242) through the oracle
+        y0 = uniform_mod(SEED + 50 + l, n, prime) if prime else splitmix64(SEED + 50 + l, n) & np.uint64((1 << l) - 1)
+        y1 = z()
+        ol.mmo_ideal_cot(A(y0), A(corr), A(choice), n, l, prime, 1 if prime else 0, A(y1))
+        return y0, y1
+
+    # Ring2Field (truncation.cpp:518-581): ALICE is the COT sender
+    ta, ma, ca, tb, mb, cb = z(), z(np.uint8), z(), z(), z(np.uint8), z()
+    ol.mmo_r2f_pre(1, A(xa), n, bw, p, A(ta), A(ma), A(ca))
+    ol.mmo_r2f_pre(2, A(xb), n, bw, p, A(tb), A(mb), A(cb))
+    from openmm_amd import lib as L
+    lib = L.load_library()
+    d_t, d_m, d_c = dev(z()), torch.zeros(n, dtype=torch.uint8, device="cuda"), dev(z())
+    L.check(lib.mmh_r2f_pre(1, L.dptr(dev(xa)), n, bw, p, L.dptr(d_t), L.dptr(d_m), L.dptr(d_c), L._stream_ptr()))
+    assert np.array_equal(host(d_t), ta) and np.array_equal(d_m.cpu().numpy(), ma) and np.array_equal(host(d_c), ca)
+    ya, yb = ideal_cot(ca, mb, 0, p)
+    fa, fb = z(), z()
+    ol.mmo_r2f_post(1, A(ta), A(ma), A(ya), n, bw, p, A(fa))
+    ol.mmo_r2f_post(2, A(tb), A(mb), A(yb), n, bw, p, A(fb))
+    # CheetahLinear::bn (cheetah-api.cpp:527-603)
+    a, e = rns_uniform(o, SEED + 43, bn.n_ct, 2), noise(SEED + 44, (bn.n_ct, N))
+    ref_cts = bn.encrypt(sk, fb, a, e)
+    got_cts = client.encryptVectorFromRing(2, (dev(tb), dev(mb), dev(yb)), bw, meta, (dev(a), dev(e)))
+    assert np.array_equal(host(got_cts), ref_cts)
+    ref_in = bn.encode(fa)
+    got_in = server.encodeVectorFromRing(1, (dev(ta), dev(ma), dev(ya)), bw, meta)
+    assert np.array_equal(host(got_in), ref_in)
+    ref_sc, got_sc = bn.encode(scale_f), server.encodeScales(dev(scale_f), meta)
+    assert np.array_equal(host(got_sc), ref_sc)
+    rnd = splitmix64(SEED + 45, n)
+    ref_out, ref_share = bn.bn(ref_cts, ref_in, ref_sc, rnd)
+    got_out, got_share = server.bn(got_cts, got_in, got_sc, meta, dev(rnd))
+    assert np.array_equal(host(got_out), ref_out) and np.array_equal(host(got_share), ref_share)
+    # Field2Ring_with_Truncate (truncation.cpp:639-695), shift = kScale
+    dec = bn.decrypt(np.ascontiguousarray(sk[:1]), ref_out)
+    ol.mmo_f2r_pre(1, A(ref_share), n, p, k, A(ta), A(ma), A(ca))
+    ol.mmo_f2r_pre(2, A(dec), n, p, k, A(tb), A(mb), A(cb))
+    g_tb, g_mb, _ = client.decryptToVectorForRing(got_out, meta, 2, k)
+    assert np.array_equal(host(g_tb), tb) and np.array_equal(g_mb.cpu().numpy(), mb)
+    L.check(lib.mmh_f2r_pre(1, L.dptr(got_share), n, p, k, L.dptr(d_t), L.dptr(d_m), L.dptr(d_c), L._stream_ptr()))
+    assert np.array_equal(host(d_t), ta) and np.array_equal(d_m.cpu().numpy(), ma) and np.array_equal(host(d_c), ca)
+    ya, yb = ideal_cot(ca, mb, bw, 0)
+    oa, ob = z(), z()
+    ol.mmo_f2r_trunc_post(1, A(ta), A(ma), A(ya), n, p, bw, k, A(oa))
+    ol.mmo_f2r_trunc_post(2, A(tb), A(mb), A(yb), n, p, bw, k, A(ob))
+    d_oa, d_ob = dev(z()), dev(z())
+    L.check(lib.mmh_f2r_trunc_post(1, L.dptr(d_t), L.dptr(d_m), L.dptr(dev(ya)), n, p, bw, k, L.dptr(d_oa), L._stream_ptr()))
+    L.check(lib.mmh_f2r_trunc_post(2, L.dptr(g_tb), L.dptr(g_mb), L.dptr(dev(yb)), n, p, bw, k, L.dptr(d_ob),
+                                   L._stream_ptr()))
+    assert np.array_equal(host(d_oa), oa) and np.array_equal(host(d_ob), ob)
+    got = (oa + ob) & ring
+    got = np.where(got >> np.uint64(bw - 1), got.astype(np.int64) - (1 << bw), got.astype(np.int64))
+    want = (x * sc) >> k   # floor
+    assert np.abs(got - want).max() <= 1
+
+
 def test_bole_full_size_identity(mm):
     """bole_test flags 1 1 size: 2^20 elements, l=32, |x|,|y| < 2^12 (tests/bole_test.cpp:78,98,568)"""
     import torch

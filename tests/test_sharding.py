@@ -92,6 +92,62 @@ def test_sharded_conv_gloo(world, n_filters):
     assert q.get(timeout=5) == (True, True, True)
 
 
+class FailingServer(FakeServer):
+    """raises the reference's zero-filter error (conv2DOneFilter :573-580) for a slice that holds an all-zero filter"""
+
+    def conv2DSSFromTensors(self, s0, share, f, meta, rand, out=None):
+        if bool((f.reshape(f.shape[0], -1) == 0).all(1).any()):
+            raise ValueError("conv2DSS: a filter is all zero")
+        return super().conv2DSSFromTensors(s0, share, f, meta, rand, out=out)
+
+
+def _worker_zero_filter(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openmm_amd.hom_conv2d_ss import Meta
+    from openmm_amd.sharding import ShardedConv
+    try:
+        n_filters = 6
+        filters = torch.arange(n_filters * 2 * 3 * 3, dtype=torch.int64).reshape(n_filters, 2, 3, 3) + 1
+        filters[n_filters - 1] = 0           # lives in the LAST rank's slice only
+        meta = Meta((2, 8, 8), (2, 3, 3), n_filters, 1, 1, True)
+        s0 = torch.zeros((2, 2, 2, 4), dtype=torch.int64)
+        got = []
+        for mode in ("gather", "d2h"):
+            sc = ShardedConv(FailingServer(), meta, mode=mode)
+            try:
+                sc.run(s0, s0, filters, lambda n: (5,))
+                got.append("no error")
+            except ValueError:
+                got.append("own")
+            except RuntimeError:
+                got.append("peer")
+            filters_ok = filters.clone()
+            filters_ok[n_filters - 1] = 1
+            cts, share = sc.run(s0, s0, filters_ok, lambda n: (5,))   # and the object still works afterwards
+            got.append(cts is not None if rank == 0 else cts is None)
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_error_on_one_rank_is_raised_on_every_rank():
+    """a rank whose filter slice fails must not leave the others inside the collective"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_zero_filter, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res[2] == ["own", True, "own", True]
+    assert res[0] == ["peer", True, "peer", True] and res[1] == ["peer", True, "peer", True]
+
+
 def test_shard_range_matches_launchworks():
     from openmm_amd.sharding import shard_range
     for n in (0, 1, 7, 64, 65):
