@@ -5,6 +5,11 @@
 // shares (NHWC) with synthetic weights; a sample of outputs is reconstructed and compared with the
 // cleartext convolution (|err| <= 1, library_fixed_uniform_cheetah.cpp:199).  Prints per-network totals.
 // ResNet50 also runs its FC 2048 -> 1001 through MatMul2D (networks/main_resnet50.cpp:6333), every output checked.
+// The live batch-norm layers run where the networks run them (ResNet50: the 18 FusedBatchNorm4411 that USE_FUSED_BN
+// leaves, networks/main_resnet50.cpp:4996-6311; DenseNet121: all 63, main_densenet121.cpp:9721-11879) through
+// ElemWiseActModelVectorMult = Ring2Field -> CheetahLinear::bn -> Field2Ring_with_Truncate
+// (library_fixed_uniform_cheetah.cpp:567-600), the conversions' COTs over mm::SilentOT (device post-processing) on an
+// ideal Ferret; every element is checked against (x * scale) >> kScale within one unit (tests/bole_test.cpp:286-289).
 //   usage: network_linear [sqnet|resnet50|densenet121] [samples per layer = 512]
 #include <chrono>
 #include <cstdio>
@@ -16,6 +21,7 @@
 #include <vector>
 
 #include "mm_gemini/library.h"
+#include "mm_gemini/silent_ot.h"
 
 using u64 = uint64_t;
 struct Shape { int C, H, W, fh, fw, M, pad, stride, count; };  // pad: zPad on each side (0 = VALID)
@@ -56,19 +62,74 @@ static int64_t to_signed(u64 v, int bw) {
   return (v >> (bw - 1)) ? (int64_t)v - (int64_t)(1ULL << bw) : (int64_t)v;
 }
 
+// one linear call of a network in program order: a convolution, a live batch-norm on n elements, or the FC
+struct Call { int kind; Shape sh; int n; };  // kind 0 conv, 1 bn, 2 fc
+
+static std::vector<Call> order_of(const Shape *net, size_t n_shapes) {  // a shape table walked count times each
+  std::vector<Call> v;
+  for (size_t k = 0; k < n_shapes; ++k)
+    for (int r = 0; r < net[k].count; ++r) v.push_back({0, net[k], 0});
+  return v;
+}
+// networks/main_resnet50.cpp:4981-6333 with USE_FUSED_BN 1: FusedBN = a convolution with its batch-norm folded in
+static std::vector<Call> resnet50_order() {
+  std::vector<Call> v;
+  auto c = [&](int C, int H, int W, int fh, int fw, int M, int pad, int st) { v.push_back({0, {C, H, W, fh, fw, M, pad, st, 1}, 0}); };
+  auto bn = [&](int h, int w, int ch) { v.push_back({1, {}, h * w * ch}); };
+  c(3, 230, 230, 7, 7, 64, 0, 2), bn(56, 56, 64);
+  c(64, 56, 56, 1, 1, 256, 0, 1), c(64, 56, 56, 1, 1, 64, 0, 1), c(64, 56, 56, 3, 3, 64, 1, 1), c(64, 56, 56, 1, 1, 256, 0, 1), bn(56, 56, 256);
+  for (int i = 0; i < 2; ++i) c(256, 56, 56, 1, 1, 64, 0, 1), c(64, 56, 56, 3, 3, 64, 1, 1), c(64, 56, 56, 1, 1, 256, 0, 1), bn(56, 56, 256);
+  c(256, 56, 56, 1, 1, 512, 0, 2), c(256, 56, 56, 1, 1, 128, 0, 1), c(128, 58, 58, 3, 3, 128, 0, 2), c(128, 28, 28, 1, 1, 512, 0, 1), bn(28, 28, 512);
+  c(512, 28, 28, 1, 1, 128, 0, 1), c(128, 28, 28, 3, 3, 128, 1, 1), bn(28, 28, 128), c(128, 28, 28, 1, 1, 512, 0, 1), bn(28, 28, 512);
+  for (int i = 0; i < 2; ++i) c(512, 28, 28, 1, 1, 128, 0, 1), c(128, 28, 28, 3, 3, 128, 1, 1), c(128, 28, 28, 1, 1, 512, 0, 1), bn(28, 28, 512);
+  c(512, 28, 28, 1, 1, 1024, 0, 2), c(512, 28, 28, 1, 1, 256, 0, 1), c(256, 30, 30, 3, 3, 256, 0, 2), c(256, 14, 14, 1, 1, 1024, 0, 1), bn(14, 14, 1024);
+  for (int i = 0; i < 5; ++i) c(1024, 14, 14, 1, 1, 256, 0, 1), c(256, 14, 14, 3, 3, 256, 1, 1), c(256, 14, 14, 1, 1, 1024, 0, 1), bn(14, 14, 1024);
+  c(1024, 14, 14, 1, 1, 2048, 0, 2), c(1024, 14, 14, 1, 1, 512, 0, 1), c(512, 16, 16, 3, 3, 512, 0, 2), c(512, 7, 7, 1, 1, 2048, 0, 1), bn(7, 7, 2048);
+  for (int i = 0; i < 2; ++i) c(2048, 7, 7, 1, 1, 512, 0, 1), c(512, 7, 7, 3, 3, 512, 1, 1), c(512, 7, 7, 1, 1, 2048, 0, 1), bn(7, 7, 2048);
+  v.push_back({2, {}, 0});
+  return v;
+}
+// networks/main_densenet121.cpp:9704-11894: a batch-norm on the concatenated features in front of every bottleneck
+// (63 live calls: one bottleneck, 28x28 with 224 channels, also keeps its own, :10074-10081)
+static std::vector<Call> densenet121_order() {
+  std::vector<Call> v{{0, {3, 224, 224, 7, 7, 64, 3, 2, 1}, 0}};
+  const int hw[4] = {56, 28, 14, 7}, c0[4] = {64, 128, 256, 512}, layers[4] = {6, 12, 24, 16}, trans[4] = {128, 256, 512, 0};
+  for (int b = 0; b < 4; ++b) {
+    for (int k = 0; k < layers[b]; ++k) {
+      const int ch = c0[b] + 32 * k;
+      v.push_back({1, {}, hw[b] * hw[b] * ch});
+      v.push_back({0, {ch, hw[b], hw[b], 1, 1, 128, 0, 1, 1}, 0});
+      if (hw[b] == 28 && ch == 224) v.push_back({1, {}, hw[b] * hw[b] * 128});
+      v.push_back({0, {128, hw[b], hw[b], 3, 3, 32, 1, 1, 1}, 0});
+    }
+    v.push_back({1, {}, hw[b] * hw[b] * (c0[b] + 32 * layers[b])});
+    if (trans[b]) v.push_back({0, {c0[b] + 32 * layers[b], hw[b], hw[b], 1, 1, trans[b], 0, 1, 1}, 0});
+  }
+  v.push_back({0, {1024, 1, 1, 1, 1, 1000, 0, 1, 1}, 0});
+  return v;
+}
+
 int main(int argc, char **argv) {
   const bool resnet = argc > 1 && !std::strcmp(argv[1], "resnet50");
   const bool densenet = argc > 1 && !std::strcmp(argv[1], "densenet121");
   const int samples = argc > 2 ? std::atoi(argv[2]) : 512;
-  const std::vector<Shape> dense = densenet121();
-  const Shape *net = densenet ? dense.data() : (resnet ? kResnet50 : kSqnet);
-  const size_t n_shapes = densenet ? dense.size() : (resnet ? sizeof(kResnet50) / sizeof(Shape) : sizeof(kSqnet) / sizeof(Shape));
-  const int l = 37;
+  const std::vector<Call> calls = densenet ? densenet121_order()
+                                           : (resnet ? resnet50_order() : order_of(kSqnet, sizeof(kSqnet) / sizeof(Shape)));
+  (void)densenet121;
+  (void)kResnet50;
+  const int l = 37, ks = 12;
   const u64 mask = (1ULL << l) - 1;
   std::mt19937_64 rng(0x4D264D);
 
   auto ios = mm::LoopbackIO::MakePair();
   std::unique_ptr<mm::LoopbackIO> io[2] = {std::move(ios.first), std::move(ios.second)};
+  // the conversions' COTs on a channel of their own, as the reference gives every Truncation its own NetIO
+  auto cios = mm::LoopbackIO::MakePair();
+  std::unique_ptr<mm::LoopbackIO> cio[2] = {std::move(cios.first), std::move(cios.second)};
+  auto fbox = std::make_shared<mm::IdealFerret::Mailbox>();
+  mm::IdealFerret ferret[2] = {mm::IdealFerret(fbox, 11), mm::IdealFerret(fbox, 12)};
+  std::unique_ptr<mm::SilentOT> ot[2];
+  std::unique_ptr<mm::Truncation> trunc[2];
   std::unique_ptr<gemini::CheetahLinear> linear[2];
   mm::Library lib[2];
   auto both = [&](const std::function<void(int)> &fn) {
@@ -82,20 +143,73 @@ int main(int argc, char **argv) {
   };
   both([&](int s) {
     linear[s].reset(new gemini::CheetahLinear(s + 1, io[s].get(), 1ULL << l));
-    lib[s].party = s + 1, lib[s].bitlength = l, lib[s].kScale = 12, lib[s].prime_mod = 1ULL << l;
-    lib[s].field_mod = linear[s]->field_mod(), lib[s].cheetah_linear = linear[s].get();
+    ot[s].reset(new mm::SilentOT(&ferret[s], cio[s].get()));
+    trunc[s].reset(new mm::Truncation(s + 1, ot[s].get()));
+    lib[s].party = s + 1, lib[s].bitlength = l, lib[s].kScale = ks, lib[s].prime_mod = 1ULL << l;
+    lib[s].field_mod = linear[s]->field_mod(), lib[s].cheetah_linear = linear[s].get(), lib[s].truncation = trunc[s].get();
   });
 
-  int layers = 0, failures = 0;
-  double total_ms = 0, cold_ms = 0;
+  int layers = 0, bns = 0, failures = 0;
+  double total_ms = 0, cold_ms = 0, bn_ms = 0;
   uint64_t transport0 = 0, bytes0 = 0;
   // pass 0 is the first inference after start-up (per shape: geometry tables, first device and page-locked
   // allocations); pass 1 is what every later inference costs and is the figure reported
   for (int pass = 0; pass < 2; ++pass) {
-  if (pass == 1) cold_ms = total_ms, total_ms = 0, layers = 0, transport0 = io[0]->transport_ns(), bytes0 = io[0]->counter + io[1]->counter;
+  if (pass == 1) {
+    cold_ms = total_ms, total_ms = 0, bn_ms = 0, layers = 0, bns = 0;
+    transport0 = io[0]->transport_ns() + cio[0]->transport_ns();
+    bytes0 = io[0]->counter + io[1]->counter + cio[0]->counter + cio[1]->counter;
+  }
   rng.seed(0x4D264D);
-  for (size_t k = 0; k < n_shapes; ++k) {
-    const Shape &sh = net[k];
+  bool first = true;
+  for (const Call &call : calls) {
+    if (call.kind == 1) {  // ElemWiseActModelVectorMult on n elements: activations and scales at scale 2^12
+      const int n = call.n;
+      std::vector<int64_t> v(n), sc(n);
+      std::vector<u64> vs[2] = {std::vector<u64>(n), std::vector<u64>(n)}, scu(n), eo[2] = {std::vector<u64>(n), std::vector<u64>(n)};
+      for (int i = 0; i < n; ++i) {
+        v[i] = (int64_t)(rng() % (1 << 21)) - (1 << 20), sc[i] = (int64_t)(rng() % (1 << 14)) - (1 << 13);
+        vs[0][i] = rng() & mask, vs[1][i] = ((u64)v[i] - vs[0][i]) & mask, scu[i] = (u64)sc[i];
+      }
+      lib[0].kIsSharedInput = lib[1].kIsSharedInput = true;
+      const auto t0 = std::chrono::steady_clock::now();
+      both([&](int s) { ElemWiseActModelVectorMult(n, vs[s].data(), scu.data(), eo[s].data()); });
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      bool ok = true;
+      for (int i = 0; i < n && ok; ++i) ok = std::llabs(to_signed(eo[0][i] + eo[1][i], l) - ((v[i] * sc[i]) >> ks)) <= 1;
+      if (!ok) ++failures;
+      if (pass == 1 || !ok)
+        std::printf("%s bn   %8d elements (Ring2Field, bn, Field2Ring_with_Truncate): %8.2f ms host-to-host\n",
+                    ok ? "PASS" : "FAIL", n, ms);
+      total_ms += ms, bn_ms += ms, ++bns;
+      continue;
+    }
+    if (call.kind == 2) {  // FC 2048 -> 1001 on the pooled features: MatMul2D(1, 2048, 1001, x, W, out, false)
+      const int in = 2048, outn = 1001;
+      std::vector<int64_t> x(in), w((size_t)in * outn);
+      std::vector<u64> xs[2] = {std::vector<u64>(in), std::vector<u64>(in)}, wu(w.size());
+      std::vector<u64> out[2] = {std::vector<u64>(in), std::vector<u64>(in)};  // row stride = input columns (:126-127)
+      for (int i = 0; i < in; ++i) {
+        x[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11);
+        xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
+      }
+      for (size_t i = 0; i < w.size(); ++i) w[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11), wu[i] = (u64)w[i];
+      lib[0].kIsSharedInput = lib[1].kIsSharedInput = true;
+      const auto t0 = std::chrono::steady_clock::now();
+      both([&](int s) { MatMul2D(1, in, outn, xs[s].data(), wu.data(), out[s].data(), false); });
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      bool ok = true;
+      for (int m = 0; m < outn && ok; ++m) {
+        int64_t acc = 0;
+        for (int c = 0; c < in; ++c) acc += x[c] * w[(size_t)c * outn + m];
+        ok = std::llabs(to_signed(out[0][m] + out[1][m], l) - acc) <= 1;
+      }
+      if (!ok) ++failures;
+      if (pass == 1 || !ok) std::printf("%s fc   2048 -> 1001 through MatMul2D: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", ms);
+      total_ms += ms;
+      continue;
+    }
+    const Shape &sh = call.sh;
     const int oh = (sh.H + 2 * sh.pad - sh.fh) / sh.stride + 1, ow = (sh.W + 2 * sh.pad - sh.fw) / sh.stride + 1;
     const size_t n_in = (size_t)sh.H * sh.W * sh.C, n_w = (size_t)sh.fh * sh.fw * sh.C * sh.M, n_out = (size_t)oh * ow * sh.M;
     std::vector<int64_t> x(n_in), w(n_w);
@@ -106,21 +220,18 @@ int main(int argc, char **argv) {
       xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
     }
     for (size_t i = 0; i < n_w; ++i) w[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11) + (i % 7 == 0), wu[i] = (u64)w[i];
-    const bool first = k == 0;  // the networks run their first layer on the client's plain input
-    if (first) {
+    if (first) {  // the networks run their first layer on the client's plain input
       for (size_t i = 0; i < n_in; ++i) xs[1][i] = (u64)x[i] & mask, xs[0][i] = 0;
     }
     lib[0].kIsSharedInput = lib[1].kIsSharedInput = !first;
-    double ms = 0;
-    for (int rep = 0; rep < sh.count; ++rep) {
-      const auto t0 = std::chrono::steady_clock::now();
-      both([&](int s) {
-        Conv2DWrapper(1, sh.H, sh.W, sh.C, sh.fh, sh.fw, sh.M, sh.pad, sh.pad, sh.pad, sh.pad, sh.stride, sh.stride,
-                      xs[s].data(), wu.data(), out[s].data());
-      });
-      ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      ++layers;
-    }
+    first = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    both([&](int s) {
+      Conv2DWrapper(1, sh.H, sh.W, sh.C, sh.fh, sh.fw, sh.M, sh.pad, sh.pad, sh.pad, sh.pad, sh.stride, sh.stride,
+                    xs[s].data(), wu.data(), out[s].data());
+    });
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++layers;
     bool ok = true;
     for (int t = 0; t < samples && ok; ++t) {
       const int y = (int)(rng() % oh), xx = (int)(rng() % ow), m = (int)(rng() % sh.M);
@@ -137,41 +248,20 @@ int main(int argc, char **argv) {
     }
     if (!ok) ++failures;
     if (pass == 1 || !ok)
-      std::printf("%s conv %4dx%3dx%3d %dx%d -> %4d s%d x%d: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", sh.C, sh.H,
-                  sh.W, sh.fh, sh.fw, sh.M, sh.stride, sh.count, ms);
+      std::printf("%s conv %4dx%3dx%3d %dx%d -> %4d s%d: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", sh.C, sh.H,
+                  sh.W, sh.fh, sh.fw, sh.M, sh.stride, ms);
     total_ms += ms;
   }
-  }
-  if (resnet) {  // FC 2048 -> 1001 on the pooled features: MatMul2D(1, 2048, 1001, x, W, out, false)
-    const int in = 2048, outn = 1001;
-    std::vector<int64_t> x(in), w((size_t)in * outn);
-    std::vector<u64> xs[2] = {std::vector<u64>(in), std::vector<u64>(in)}, wu(w.size());
-    std::vector<u64> out[2] = {std::vector<u64>(in), std::vector<u64>(in)};  // row stride = input columns (:126-127)
-    for (int i = 0; i < in; ++i) {
-      x[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11);
-      xs[0][i] = rng() & mask, xs[1][i] = ((u64)x[i] - xs[0][i]) & mask;
-    }
-    for (size_t i = 0; i < w.size(); ++i) w[i] = (int64_t)(rng() % (1 << 12)) - (1 << 11), wu[i] = (u64)w[i];
-    lib[0].kIsSharedInput = lib[1].kIsSharedInput = true;
-    const auto t0 = std::chrono::steady_clock::now();
-    both([&](int s) { MatMul2D(1, in, outn, xs[s].data(), wu.data(), out[s].data(), false); });
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    bool ok = true;
-    for (int m = 0; m < outn && ok; ++m) {
-      int64_t acc = 0;
-      for (int c = 0; c < in; ++c) acc += x[c] * w[(size_t)c * outn + m];
-      ok = std::llabs(to_signed(out[0][m] + out[1][m], l) - acc) <= 1;
-    }
-    if (!ok) ++failures;
-    std::printf("%s fc   2048 -> 1001 through MatMul2D: %8.2f ms host-to-host\n", ok ? "PASS" : "FAIL", ms);
-    total_ms += ms;
   }
   std::printf("first inference after start-up: %.1f ms\n", cold_ms);
   std::printf("in-process transport (the byte pipe's copies, the stand-in for the network): %.1f ms for %.1f MiB both ways\n",
-              (io[0]->transport_ns() - transport0) * 1e-6, (io[0]->counter + io[1]->counter - bytes0) / 1048576.0);
+              (io[0]->transport_ns() + cio[0]->transport_ns() - transport0) * 1e-6,
+              (io[0]->counter + io[1]->counter + cio[0]->counter + cio[1]->counter - bytes0) / 1048576.0);
   std::printf("%s: %d convolutions through Conv2DWrapper, both parties in-process, %.1f ms in total (host tensors in,\n"
               "host tensors out, encryption, transport through a byte pipe and decryption included)\n",
-              densenet ? "DenseNet121" : (resnet ? "ResNet50" : "SqueezeNet"), layers, total_ms);
+              densenet ? "DenseNet121" : (resnet ? "ResNet50" : "SqueezeNet"), layers, total_ms - bn_ms);
+  std::printf("%d live batch-norm layers through ElemWiseActModelVectorMult: %.1f ms; whole linear part in network order: %.1f ms\n",
+              bns, bn_ms, total_ms);
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL PASSED", failures);
   return failures ? 1 : 0;
 }

@@ -1,12 +1,22 @@
 #!/usr/bin/env python3
-"""The ResNet50 leg of bench.py alone (fresh filters, one GPU), for rocprofv3 --kernel-trace --stats."""
+"""One network's linear calls in network order (bench.py's in-order leg: convolutions, FC, live batch-norms, randomness
+sampled inside every call), a few passes, for rocprofv3 --kernel-trace --stats: the per-kernel share of the leg.
+usage: resnet_prof.py [resnet50|densenet121|squeezenet] [passes=5]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import openmm_amd
 import bench
-bench.LAYER_PREWARM_S = 0.0   # the same number of calls for every layer shape: the kernel shares are per pass over the shapes
-out = bench.resnet50_leg(torch, None, openmm_amd, 0, 1, 0, reps=5, prepared=False)
-print({k: v for k, v in out.items() if k != "resnet50_conv_ms_per_shape"})
-print(out["resnet50_conv_ms_per_shape"])
+which = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+order = {"resnet50": bench.resnet50_order, "densenet121": bench.densenet121_order, "squeezenet": bench.squeezenet_order}[which]()
+net = bench.NetworkLegs(torch, openmm_amd, 0)
+calls = [net.conv_call(a) if k == "conv" else (net.bn_call(a) if k == "bn" else net.fc_call(*a)) for k, a in order]
+import time
+for p in range(passes + 1):
+    t0 = time.perf_counter()
+    for f in calls:
+        f()
+    torch.cuda.synchronize()
+    print(f"pass {p}: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
