@@ -448,7 +448,7 @@ class NetworkLegs:
 
     def draw(self, n_out):
         """(u, e1, mask) for n_out output ciphertexts, sampled now on the device (mmh_sample_*)"""
-        return self.sampler.ternary(n_out), self.sampler.noise(n_out), self.sampler.uniform(n_out, lv=1)
+        return self.sampler.reshare(n_out)
 
     def conv_inputs(self, shape):
         from openmm_amd.hom_conv2d_ss import Meta

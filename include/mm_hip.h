@@ -251,6 +251,12 @@ int mmh_sample_noise(const uint32_t key[8], uint64_t stream_id, int64_t *d_out, 
 /* seal::util::sample_poly_uniform (hom_conv2d_ss.cc:206): [n_polys][limbs(lv)][N], limb l < q_l */
 int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key[8], uint64_t stream_id, uint64_t *d_out,
                        size_t n_polys, void *stream);
+/* The randomness of n re-sharings in ONE launch (conv2DSS / matVecMul draw it per output ciphertext,
+ * hom_conv2d_ss.cc:275-340,:180-223): d_u = mmh_sample_ternary(key, stream_id), d_e1 = mmh_sample_noise(key,
+ * stream_id + 1), d_mask = mmh_sample_uniform(ctx, 1, key, stream_id + 2), each [n][N]; the same values as the three
+ * calls (tests/test_sampler_gpu.py).  The caller advances its stream id by 3. */
+int mmh_sample_reshare(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t n, int64_t *d_u,
+                       int64_t *d_e1, uint64_t *d_mask, void *stream);
 /* signed small polynomials [n][N] -> RNS + forward NTT [n][limbs][N]: secret key to NTT form
  * (seal::KeyGenerator, cheetah-api.cpp:109-111) */
 int mmh_signed_to_ntt(const mmh_ctx *ctx, int lv, const int64_t *d_signed, size_t n, uint64_t *d_out,

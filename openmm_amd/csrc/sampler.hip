@@ -37,42 +37,101 @@ __device__ __forceinline__ void chacha20_block(const ChaChaKey &key, u64 stream_
   for (int i = 0; i < 8; ++i) out[i] = (u64)(x[2 * i] + in[2 * i]) | ((u64)(x[2 * i + 1] + in[2 * i + 1]) << 32);
 }
 
-// MODE 0: raw words; 1: ternary in {-1,0,1}; 2: centred binomial (21 - 21 bits)
-template <int MODE>
-__global__ __launch_bounds__(256) void sample_words_kernel(ChaChaKey key, u64 stream_id, u64 counter0, u64 *out,
-                                                           size_t n_words) {
+// Raw keystream: block b = words 8b .. 8b+7 (what the RFC's test vector pins)
+__global__ __launch_bounds__(256) void sample_raw_kernel(ChaChaKey key, u64 stream_id, u64 counter0, u64 *out,
+                                                         size_t n_words) {
   const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (blk * 8 >= n_words) return;
   u64 w[8];
   chacha20_block(key, stream_id, counter0 + blk, w);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const size_t idx = blk * 8 + i;
-    if (idx >= n_words) break;
-    u64 v = w[i];
-    if (MODE == 1) v = (u64)((int64_t)mulhi64(v, 3) - 1);
-    if (MODE == 2) v = (u64)((int64_t)__popcll(v & 0x1FFFFF) - (int64_t)__popcll((v >> 21) & 0x1FFFFF));
+  for (int i = 0; i < 8; ++i)
+    if (blk * 8 + i < n_words) out[blk * 8 + i] = w[i];
+}
+
+// The three distributions, each spending the keystream bits its samples need and no more (a ChaCha20 block costs
+// ~1000 vector instructions per lane; the re-sharing of one output ciphertext draws 3 x 4096 samples):
+//   ternary  16 per block: a 32-bit word w -> floor(3 w / 2^32) - 1   (each value within 2^-32 of 1/3)
+//   noise    12 per block: 42 bits -> popcount(21 bits) - popcount(21 bits)   (SEAL's sample_poly_cbd, exact)
+//   uniform   8 per block: a 64-bit word w below the largest multiple of q -> w mod q (exact); the word is rejected
+//             with probability < q / 2^64 and the sample then comes from 128 bits of a block of its own
+// Block -> sample index: thread t of the 256-thread tile T computes block counter0 + 256 T + t, and its j-th sample
+// is element (256 W) T + 256 j + t of the output (W samples per block), so every store instruction of a wave writes
+// 64 consecutive words.  The fused launch below and the stand-alone entry points share these functions, hence agree.
+constexpr int kTernaryPerBlock = 16, kNoisePerBlock = 12, kUniformPerBlock = 8;
+
+__device__ __forceinline__ void ternary_block(const ChaChaKey &key, u64 sid, u64 counter0, size_t tile, int t,
+                                              int64_t *out, size_t n) {
+  u64 w[8];
+  chacha20_block(key, sid, counter0 + tile * 256 + t, w);
+  const size_t base = tile * (256 * kTernaryPerBlock) + t;
+#pragma unroll
+  for (int j = 0; j < kTernaryPerBlock; ++j) {
+    const u32 r = (u32)(w[j >> 1] >> ((j & 1) * 32));
+    const size_t idx = base + (size_t)j * 256;
+    if (idx < n) out[idx] = (int64_t)__umulhi(r, 3u) - 1;
+  }
+}
+__device__ __forceinline__ void noise_block(const ChaChaKey &key, u64 sid, u64 counter0, size_t tile, int t,
+                                            int64_t *out, size_t n) {
+  u64 w[8];
+  chacha20_block(key, sid, counter0 + tile * 256 + t, w);
+  const size_t base = tile * (256 * kNoisePerBlock) + t;
+#pragma unroll
+  for (int j = 0; j < kNoisePerBlock; ++j) {
+    const int bit = 42 * j, a = bit >> 6, sh = bit & 63;
+    u64 v = w[a] >> sh;
+    if (sh > 22) v |= w[a + 1] << (64 - sh);   // (a + 1 <= 7: 42 * 12 = 504 bits)
+    const size_t idx = base + (size_t)j * 256;
+    if (idx < n) out[idx] = (int64_t)__popcll(v & 0x1FFFFF) - (int64_t)__popcll((v >> 21) & 0x1FFFFF);
+  }
+}
+__device__ __forceinline__ void uniform_block(const ChaChaKey &key, u64 sid, u64 counter0, size_t tile, int t, u64 *out,
+                                              size_t n, int logN, int limbs, const DevMod *__restrict__ mods) {
+  u64 w[8];
+  chacha20_block(key, sid, counter0 + tile * 256 + t, w);
+  const size_t base = tile * (256 * kUniformPerBlock) + t;
+#pragma unroll
+  for (int j = 0; j < kUniformPerBlock; ++j) {
+    const size_t idx = base + (size_t)j * 256;
+    if (idx >= n) continue;
+    const DevMod &q = mods[(idx >> logN) % limbs];
+    u64 v;
+    if (w[j] < q.q * q.barrett_hi) {   // barrett_hi = floor(2^64 / q): below the largest multiple of q
+      v = reduce64(w[j], q);
+    } else {                           // (probability < q / 2^64) 128 fresh bits from a block only this sample uses
+      u64 x[8];
+      chacha20_block(key, sid, (u64(1) << 63) | idx, x);
+      v = csub(barrett128(reduce64(x[1], q), x[0], q.q, q.barrett_hi, q.barrett_lo), q.q);
+    }
     out[idx] = v;
   }
 }
 
-// uniform in [0, q_l): 128 keystream bits reduced mod q_l (statistical distance < 2^-64)
+// MODE 1: ternary in {-1,0,1}; 2: centred binomial (21 - 21 bits)
+template <int MODE>
+__global__ __launch_bounds__(256) void sample_words_kernel(ChaChaKey key, u64 stream_id, u64 counter0, u64 *out,
+                                                           size_t n_words) {
+  if (MODE == 1) ternary_block(key, stream_id, counter0, blockIdx.x, threadIdx.x, (int64_t *)out, n_words);
+  if (MODE == 2) noise_block(key, stream_id, counter0, blockIdx.x, threadIdx.x, (int64_t *)out, n_words);
+}
+
+// uniform in [0, q_l)
 __global__ __launch_bounds__(256) void sample_uniform_kernel(ChaChaKey key, u64 stream_id, u64 counter0, u64 *out,
                                                              size_t total, int logN, int limbs,
                                                              const DevMod *__restrict__ mods) {
-  const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;  // 4 coefficients per block
-  if (blk * 4 >= total) return;
-  u64 w[8];
-  chacha20_block(key, stream_id, counter0 + blk, w);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const size_t idx = blk * 4 + i;
-    if (idx >= total) break;
-    const DevMod &q = mods[(idx >> logN) % limbs];
-    // (hi*2^64 + lo) mod q with hi reduced first so that Barrett's quotient fits 64 bits
-    const u64 hi = reduce64(w[2 * i + 1], q);
-    out[idx] = csub(barrett128(hi, w[2 * i], q.q, q.barrett_hi, q.barrett_lo), q.q);
-  }
+  uniform_block(key, stream_id, counter0, blockIdx.x, threadIdx.x, out, total, logN, limbs, mods);
+}
+
+// the randomness of n re-sharings in one launch: u = ternary(stream_id), e1 = noise(stream_id + 1), mask =
+// uniform at the last level (stream_id + 2), n polynomials of N coefficients each
+__global__ __launch_bounds__(256) void sample_reshare_kernel(ChaChaKey key, u64 stream_id, int64_t *u, int64_t *e1,
+                                                             u64 *mask, size_t total, int logN, unsigned tiles_u,
+                                                             unsigned tiles_e, const DevMod *__restrict__ mods) {
+  const unsigned b = blockIdx.x;
+  if (b < tiles_u) ternary_block(key, stream_id, 0, b, threadIdx.x, u, total);
+  else if (b < tiles_u + tiles_e) noise_block(key, stream_id + 1, 0, b - tiles_u, threadIdx.x, e1, total);
+  else uniform_block(key, stream_id + 2, 0, b - tiles_u - tiles_e, threadIdx.x, mask, total, logN, 1, mods);
 }
 
 __global__ __launch_bounds__(256) void signed_to_rns_kernel2(const int64_t *__restrict__ v, u64 *__restrict__ out,
@@ -94,16 +153,23 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 using namespace mmh;
 
+static unsigned tiles_of(size_t n, int per_block) { return (unsigned)((n + 256 * (size_t)per_block - 1) / (256 * (size_t)per_block)); }
+
 static int sample_words(int mode, const uint32_t key[8], uint64_t stream_id, uint64_t counter0, uint64_t *d_out,
                         size_t n_words, void *stream) {
   MMH_REQUIRE(key && (d_out || n_words == 0), MMH_ERR_NULL_POINTER);
   if (n_words == 0) return MMH_OK;
   ChaChaKey k;
   for (int i = 0; i < 8; ++i) k.k[i] = key[i];
-  const size_t blocks = (n_words + 7) / 8;
-  auto kern = mode == 0 ? sample_words_kernel<0> : (mode == 1 ? sample_words_kernel<1> : sample_words_kernel<2>);
-  hipLaunchKernelGGL(kern, dim3(nblk(blocks)), dim3(256), 0, (hipStream_t)stream, k, stream_id, counter0, d_out,
-                     n_words);
+  if (mode == 0)
+    hipLaunchKernelGGL(sample_raw_kernel, dim3(nblk((n_words + 7) / 8)), dim3(256), 0, (hipStream_t)stream, k, stream_id,
+                       counter0, d_out, n_words);
+  else if (mode == 1)
+    hipLaunchKernelGGL(sample_words_kernel<1>, dim3(tiles_of(n_words, kTernaryPerBlock)), dim3(256), 0,
+                       (hipStream_t)stream, k, stream_id, counter0, d_out, n_words);
+  else
+    hipLaunchKernelGGL(sample_words_kernel<2>, dim3(tiles_of(n_words, kNoisePerBlock)), dim3(256), 0,
+                       (hipStream_t)stream, k, stream_id, counter0, d_out, n_words);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
@@ -130,8 +196,23 @@ extern "C" int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key
   for (int i = 0; i < 8; ++i) k.k[i] = key[i];
   const int limbs = lv == 0 ? (int)ctx->L : 1;
   const size_t total = n_polys * limbs * ctx->N;
-  hipLaunchKernelGGL(sample_uniform_kernel, dim3(nblk((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k,
-                     stream_id, (u64)0, d_out, total, ctx->logN, limbs, ctx->d_mods);
+  hipLaunchKernelGGL(sample_uniform_kernel, dim3(tiles_of(total, kUniformPerBlock)), dim3(256), 0, (hipStream_t)stream,
+                     k, stream_id, (u64)0, d_out, total, ctx->logN, limbs, ctx->d_mods);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+extern "C" int mmh_sample_reshare(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t n, int64_t *d_u,
+                                  int64_t *d_e1, uint64_t *d_mask, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  MMH_REQUIRE(ctx && key && (n == 0 || (d_u && d_e1 && d_mask)), MMH_ERR_NULL_POINTER);
+  if (n == 0) return MMH_OK;
+  ChaChaKey k;
+  for (int i = 0; i < 8; ++i) k.k[i] = key[i];
+  const size_t total = n * ctx->N;
+  const unsigned tu = tiles_of(total, kTernaryPerBlock), te = tiles_of(total, kNoisePerBlock),
+                 tm = tiles_of(total, kUniformPerBlock);
+  hipLaunchKernelGGL(sample_reshare_kernel, dim3(tu + te + tm), dim3(256), 0, (hipStream_t)stream, k, stream_id, d_u,
+                     d_e1, d_mask, total, ctx->logN, tu, te, ctx->d_mods);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }

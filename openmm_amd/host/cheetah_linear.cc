@@ -205,6 +205,17 @@ struct CheetahLinear::Impl {
     must(mmh_sample_noise(key, sid(), (int64_t *)d.p, n * N, stream), "sample_noise");
     return d;
   }
+  // (u, e1, mask) of n re-sharings in one launch (mmh_sample_reshare)
+  struct Reshare {
+    Dev u, e1, mask;
+  };
+  Reshare reshare(size_t n) const {
+    Reshare r{mk(n * N), mk(n * N), mk(n * N)};
+    const uint64_t s0 = stream_id;
+    stream_id += 3;
+    must(mmh_sample_reshare(ring.ctx, key, s0, n, (int64_t *)r.u.p, (int64_t *)r.e1.p, r.mask.p, stream), "sample_reshare");
+    return r;
+  }
   Dev words(size_t n) const {
     Dev d = mk(n);
     must(mmh_chacha20_words(key, sid(), 0, d.p, n, stream), "chacha20");
@@ -359,7 +370,8 @@ struct CheetahLinear::Impl {
       sync();
     } else {
       // randomness and the flag are enqueued before the (blocking) receive, so they run while the client encrypts
-      Dev u = ternary(n_out), e1 = noise(n_out), mask = uniform(ring.ctx, 1, n_out);
+      Reshare rs = reshare(n_out);
+      Dev &u = rs.u, &e1 = rs.e1, &mask = rs.mask;
       Dev out_cts = mk(n_out * 2 * N), flag = mk(1);
       Dev cts = recv_fresh(ring.ctx, n_in);
       // encodeImage + encodeFilters + conv2DSS (cheetah-api.cpp:401-445) in one device call
@@ -552,7 +564,8 @@ void CheetahLinear::fc_any(const Tensor<uint64_t> &input_vector, const uint64_t 
       spts = I.mk(n_in * N);
       must(mmh_fc_encode_input(plan, vec.p, spts.p, I.stream), "CheetahLinear::fc encodeInputVector error");
     }
-    Dev u = I.ternary(n_out), e1 = I.noise(n_out), mask = I.uniform(I.ring.ctx, 1, n_out);
+    Impl::Reshare rs = I.reshare(n_out);
+    Dev &u = rs.u, &e1 = rs.e1, &mask = rs.mask;
     Dev out_cts = I.mk(n_out * 2 * N), share = I.mk(rows);
     Dev cts = I.recv_fresh(I.ring.ctx, n_in);
     must(mmh_fc_server(plan, cts.p, spts.p, wpts.p, I.ring.pk_last.p, (const int64_t *)u.p, (const int64_t *)e1.p, mask.p,

@@ -27,6 +27,7 @@ _vp, _sz, _u64, _int = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
 SIGNATURES = {
     "mmh_device_count": [C.POINTER(_int)],
     "mmh_conv_plan_work": [_vp, _vp],
+    "mmh_sample_reshare": [_vp, C.POINTER(C.c_uint32), _u64, _sz, _vp, _vp, _vp, _vp],
     "mmh_ctx_create": [C.POINTER(_vp), _sz, C.POINTER(_u64), _sz, _u64, _int],
     "mmh_ctx_create_bits": [C.POINTER(_vp), _sz, C.POINTER(_int), _sz, _u64, _int],
     "mmh_ctx_destroy": [_vp],
@@ -452,6 +453,15 @@ class Sampler:
         check(self.ctx.lib.mmh_sample_uniform(self.ctx.handle, lv, self.key, self._sid(), dptr(out), n_polys,
                                               _stream_ptr()))
         return out
+
+    def reshare(self, n_polys):
+        """(u, e1, mask) of n re-sharings in one launch = ternary, noise, uniform(lv=1) on three consecutive streams"""
+        u, e1, mask = (self.ctx._empty(n_polys, self.ctx.N) for _ in range(3))
+        sid = self.next_stream
+        self.next_stream += 3
+        check(self.ctx.lib.mmh_sample_reshare(self.ctx.handle, self.key, sid, n_polys, dptr(u), dptr(e1), dptr(mask),
+                                              _stream_ptr()))
+        return u, e1, mask
 
     def keygen(self):
         """KeyGenerator: ternary secret (NTT form) and pk = (-(a s + e), a) (cheetah-api.cpp:107-114)"""

@@ -9,7 +9,15 @@
 // leaves, networks/main_resnet50.cpp:4996-6311; DenseNet121: all 63, main_densenet121.cpp:9721-11879) through
 // ElemWiseActModelVectorMult = Ring2Field -> CheetahLinear::bn -> Field2Ring_with_Truncate
 // (library_fixed_uniform_cheetah.cpp:567-600), the conversions' COTs over mm::SilentOT (device post-processing) on an
-// ideal Ferret; every element is checked against (x * scale) >> kScale within one unit (tests/bole_test.cpp:286-289).
+// ideal Ferret; every element is checked against (x * scale) >> kScale.  The reference accepts one unit either side of
+// the quotient rounded towards zero (tests/bole_test.cpp:286-289).  What field_to_ring_with_truncate (truncation.cpp:
+// 639-695) can produce is narrower and one-sided: with A + B = v + w p over the integers, its output is
+// floor(A / 2^s) + floor(B / 2^s) + 1 - w floor(p / 2^s) = floor(v / 2^s) + 1 - c + c2, c the carry of the low parts of
+// A and B and c2 = 1 only if w = 1 and (v mod 2^s) + (p mod 2^s) >= 2^s.  Every table prime is 1 mod 2^13, so c2 = 1
+// needs v = -1 mod 2^s, and then c = 0 only when both low parts are zero: the result is floor(v / 2^s) + {0, 1} except
+// with probability ~2^-24 per element, where it is floor + 2 (the reference's own check trips on those for positive
+// values: about one run in three at ResNet50's 5.8 M elements).  The check here is that exact set, with the +2 cases
+// counted and required to be that rare.
 //   usage: network_linear [sqnet|resnet50|densenet121] [samples per layer = 512]
 #include <chrono>
 #include <cstdio>
@@ -150,6 +158,7 @@ int main(int argc, char **argv) {
   });
 
   int layers = 0, bns = 0, failures = 0;
+  long plus2_total = 0;
   double total_ms = 0, cold_ms = 0, bn_ms = 0;
   uint64_t transport0 = 0, bytes0 = 0;
   // pass 0 is the first inference after start-up (per shape: geometry tables, first device and page-locked
@@ -176,8 +185,23 @@ int main(int argc, char **argv) {
       both([&](int s) { ElemWiseActModelVectorMult(n, vs[s].data(), scu.data(), eo[s].data()); });
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       bool ok = true;
-      for (int i = 0; i < n && ok; ++i) ok = std::llabs(to_signed(eo[0][i] + eo[1][i], l) - ((v[i] * sc[i]) >> ks)) <= 1;
-      if (!ok) ++failures;
+      int bad = 0, first_bad = -1, last_bad = -1, plus2 = 0;
+      for (int i = 0; i < n; ++i) {
+        const int64_t d = to_signed(eo[0][i] + eo[1][i], l) - ((v[i] * sc[i]) >> ks);  // arithmetic shift = floor
+        if (d == 2) ++plus2;
+        if (d < 0 || d > 2) {
+          if (!bad++) first_bad = i;
+          last_bad = i;
+        }
+      }
+      plus2_total += plus2;
+      ok = bad == 0 && plus2 <= 3 + n / (1 << 20);
+      if (!ok) {
+        ++failures;
+        std::printf("     %d of %d elements outside floor + {0,1,2} (%d at + 2), first %d (got %lld, floor %lld), last %d\n", bad, n, plus2,
+                    first_bad, (long long)to_signed(eo[0][first_bad] + eo[1][first_bad], l),
+                    (long long)((v[first_bad] * sc[first_bad]) >> ks), last_bad);
+      }
       if (pass == 1 || !ok)
         std::printf("%s bn   %8d elements (Ring2Field, bn, Field2Ring_with_Truncate): %8.2f ms host-to-host\n",
                     ok ? "PASS" : "FAIL", n, ms);
@@ -262,6 +286,7 @@ int main(int argc, char **argv) {
               densenet ? "DenseNet121" : (resnet ? "ResNet50" : "SqueezeNet"), layers, total_ms - bn_ms);
   std::printf("%d live batch-norm layers through ElemWiseActModelVectorMult: %.1f ms; whole linear part in network order: %.1f ms\n",
               bns, bn_ms, total_ms);
+  if (bns) std::printf("batch-norm outputs at floor + 2 (the truncation's 2^-24 tail) over both passes: %ld\n", plus2_total);
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL PASSED", failures);
   return failures ? 1 : 0;
 }

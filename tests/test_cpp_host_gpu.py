@@ -41,6 +41,8 @@ def test_network_linear_layers_through_the_layer_adapters(net, count):
     print(r.stdout[-6000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ALL PASSED" in r.stdout and f"{count} convolutions" in r.stdout
     assert "FAIL " not in r.stdout
+    # the live batch-norms (ElemWiseActModelVectorMult = Ring2Field, bn, Field2Ring_with_Truncate) in network order
+    assert f"{18 if net == 'resnet50' else 63} live batch-norm layers" in r.stdout and "PASS bn " in r.stdout
     if net == "resnet50":
         assert "PASS fc   2048 -> 1001" in r.stdout
 

@@ -302,8 +302,12 @@ def test_network_bn_layer_bit_exact(mm, n):
     assert np.array_equal(host(d_oa), oa) and np.array_equal(host(d_ob), ob)
     got = (oa + ob) & ring
     got = np.where(got >> np.uint64(bw - 1), got.astype(np.int64) - (1 << bw), got.astype(np.int64))
-    want = (x * sc) >> k   # floor
-    assert np.abs(got - want).max() <= 1
+    # field_to_ring_with_truncate gives floor(v / 2^k) + 1 - c + c2 (c: carry of the two low parts; c2: 1 only when the
+    # wrap bit is set and v = -1 mod 2^k, p being 1 mod 2^13): floor + {0, 1}, and floor + 2 with probability ~2^-24
+    # (tests/cpp/network_linear.cc has the derivation); tests/bole_test.cpp:286-289 accepts one unit around the
+    # quotient rounded towards zero, which contains floor + {0, 1} for either sign
+    d = got - ((x * sc) >> k)
+    assert d.min() >= 0 and d.max() <= 2 and int((d == 2).sum()) <= 2
 
 
 def test_bole_full_size_identity(mm):

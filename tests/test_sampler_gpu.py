@@ -76,3 +76,49 @@ def test_distributions_and_roundtrip(mm):
     z = g.encrypt_zero_asym(pk, smp.ternary(5), smp.noise(5), smp.noise(5))
     z = g.add_plain(z, m)
     assert torch.equal(g.decrypt(sk, z), m)
+
+
+def test_reshare_launch_equals_the_three_samplers(mm):
+    """mmh_sample_reshare = ternary(sid) | noise(sid + 1) | uniform at the last level (sid + 2), same values; lengths
+    that end inside a tile of every kind"""
+    import torch
+    g = mm.Context(N, (60, 49), 1 << 37)
+    for n in (1, 3, 64):
+        a, b = mm.Sampler(g, key=bytes(range(32))), mm.Sampler(g, key=bytes(range(32)))
+        u, e1, mask = a.reshare(n)
+        assert torch.equal(u, b.ternary(n)) and torch.equal(e1, b.noise(n))
+        assert torch.equal(mask, b.uniform(n, lv=1).view(n, N))
+        assert a.next_stream == b.next_stream
+
+
+def test_sample_mapping_against_the_block_function(mm):
+    """the three distributions spend the keystream as include/mm_hip.h / sampler.hip say: thread t of tile T owns
+    block 256 T + t and its j-th sample is element 256 W T + 256 j + t (W = 16 ternary from 32-bit words, 12 noise
+    from 42-bit fields, 8 uniform from 64-bit words); checked against the RFC block function in Python"""
+    g = mm.Context(N, (60, 49), 1 << 37)
+    key = bytes(range(32))
+    kws = struct.unpack("<8I", key)
+    smp = mm.Sampler(g, key=key)
+    t = smp.ternary(2).cpu().numpy().reshape(-1)      # stream 1
+    e = smp.noise(2).cpu().numpy().reshape(-1)        # stream 2
+    u = smp.uniform(2, lv=1).cpu().numpy().view(np.uint64).reshape(-1)   # stream 3
+    q0 = g.q[0]
+    for tile, tid in ((0, 0), (0, 255), (1, 17)):
+        for sid, per, arr in ((1, 16, t), (2, 12, e), (3, 8, u)):
+            blk = chacha_block(kws, tile * 256 + tid, 0, sid, 0)
+            bits = sum(w << (32 * i) for i, w in enumerate(blk))
+            for j in range(per):
+                idx = tile * 256 * per + 256 * j + tid
+                if idx >= arr.size:
+                    continue
+                if per == 16:
+                    want = ((blk[j] * 3) >> 32) - 1
+                elif per == 12:
+                    v = (bits >> (42 * j)) & ((1 << 42) - 1)
+                    want = bin(v & 0x1FFFFF).count("1") - bin(v >> 21).count("1")
+                else:
+                    w = (bits >> (64 * j)) & ((1 << 64) - 1)
+                    if w >= q0 * ((1 << 64) // q0):
+                        continue   # (2^-46: the fallback block)
+                    want = w % q0
+                assert int(arr[idx]) == want, (sid, tile, tid, j)
