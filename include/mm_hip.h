@@ -85,6 +85,7 @@ int mmh_host_register(void *h_ptr, size_t bytes);
 int mmh_host_unregister(void *h_ptr);
 int mmh_memcpy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int mmh_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
+int mmh_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
 int mmh_memset(void *d_dst, int value, size_t bytes, void *stream);
 int mmh_stream_sync(void *stream);
 

@@ -172,6 +172,9 @@ class CoeffModulus {
 class UniformRandomGenerator {
  public:
   UniformRandomGenerator() { facade::os_random(key_, sizeof(key_)); }
+  // a generator with a caller-chosen key: what a factory made with UniformRandomGeneratorFactory(key) hands out, so
+  // that a test can replay the randomness of a call (SEAL's Blake2xbPRNGFactory(seed) plays that role there)
+  explicit UniformRandomGenerator(const std::array<std::uint32_t, 8> &key) { std::memcpy(key_, key.data(), sizeof(key_)); }
   void generate(std::size_t byte_count, seal_byte *destination) {
     if (byte_count == 0) return;
     const std::size_t words = (byte_count + 7) / 8;
@@ -196,6 +199,15 @@ class UniformRandomGenerator {
     std::lock_guard<std::mutex> g(mu_);
     *stream_id = next_stream_++;
   }
+  // the generator's own key and `count` consecutive stream ids of it, for the batched layer calls: one device sampler
+  // launch draws a whole layer's randomness from (key, first .. first + count - 1)
+  std::uint64_t take_streams(std::uint32_t key[8], std::uint64_t count) {
+    std::memcpy(key, key_, sizeof(key_));
+    std::lock_guard<std::mutex> g(mu_);
+    const std::uint64_t first = next_stream_;
+    next_stream_ += count;
+    return first;
+  }
 
  private:
   std::uint32_t key_[8];
@@ -204,11 +216,29 @@ class UniformRandomGenerator {
 };
 class UniformRandomGeneratorFactory {
  public:
-  std::shared_ptr<UniformRandomGenerator> create() const { return std::make_shared<UniformRandomGenerator>(); }
+  UniformRandomGeneratorFactory() = default;
+  // every generator this factory creates is keyed by `key` with its last word offset by the number of generators made
+  // before it: repeatable streams for tests (set through EncryptionParameters::set_random_generator)
+  explicit UniformRandomGeneratorFactory(const std::array<std::uint32_t, 8> &key) : fixed_(true), key_(key) {}
+  std::shared_ptr<UniformRandomGenerator> create() const {
+    if (!fixed_) return std::make_shared<UniformRandomGenerator>();
+    std::array<std::uint32_t, 8> k = key_;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      k[7] += made_++;
+    }
+    return std::make_shared<UniformRandomGenerator>(k);
+  }
   static std::shared_ptr<UniformRandomGeneratorFactory> DefaultFactory() {
     static std::shared_ptr<UniformRandomGeneratorFactory> f = std::make_shared<UniformRandomGeneratorFactory>();
     return f;
   }
+
+ private:
+  bool fixed_ = false;
+  std::array<std::uint32_t, 8> key_{};
+  mutable std::uint32_t made_ = 0;
+  mutable std::mutex mu_;
 };
 
 // ------------------------------------------------------------------------------------------ parameters
@@ -430,6 +460,20 @@ class SEALContext {
 };
 
 // ------------------------------------------------------------------------------------------ Plaintext / Ciphertext
+namespace facade {
+// A batch of plaintexts that exists on the device in a cheaper form than N host coefficients each (the raw filter
+// tensor of a layer, encoded vectors that never leave HBM): what the batched implementations of the protocol classes
+// (openmm_amd/dropin) hand from encodeFilters / encodeImage / encodeVector to conv2DSS / matVecMul / bn through the
+// reference's own std::vector<seal::Plaintext> arguments.  A Plaintext that is an element of such a batch behaves like
+// any other; its coefficients are brought to the host the first time somebody asks for them.
+struct LazyPlain {
+  virtual ~LazyPlain() = default;
+  virtual std::size_t coeff_count(std::size_t index) const = 0;
+  virtual bool is_zero(std::size_t index) const = 0;
+  virtual void materialize(std::size_t index, std::vector<std::uint64_t> &out) const = 0;  // coefficient form
+};
+}  // namespace facade
+
 class Plaintext {
  public:
   Plaintext() = default;
@@ -437,19 +481,25 @@ class Plaintext {
   explicit Plaintext(std::size_t coeff_count) : data_(coeff_count, 0) {}
   void resize(std::size_t coeff_count) {
     if (parms_id_ != parms_id_zero) throw std::logic_error("cannot resize an NTT transformed Plaintext");
+    realize();
     data_.resize(coeff_count, 0);
   }
-  void release() { data_.clear(), data_.shrink_to_fit(), parms_id_ = parms_id_zero; }
-  void set_zero() { std::fill(data_.begin(), data_.end(), 0); }
-  std::uint64_t *data() { return data_.data(); }
-  const std::uint64_t *data() const { return data_.data(); }
-  std::size_t coeff_count() const { return data_.size(); }
+  void release() { lazy_.reset(), data_.clear(), data_.shrink_to_fit(), parms_id_ = parms_id_zero; }
+  void set_zero() {
+    realize();
+    std::fill(data_.begin(), data_.end(), 0);
+  }
+  std::uint64_t *data() { return realize(), data_.data(); }
+  const std::uint64_t *data() const { return realize(), data_.data(); }
+  std::size_t coeff_count() const { return lazy_ ? lazy_->coeff_count(lazy_index_) : data_.size(); }
   std::size_t significant_coeff_count() const {
+    realize();
     std::size_t n = data_.size();
     while (n && data_[n - 1] == 0) --n;
     return n;
   }
   bool is_zero() const {
+    if (lazy_) return lazy_->is_zero(lazy_index_);
     return data_.empty() || std::all_of(data_.begin(), data_.end(), [](std::uint64_t c) { return c == 0; });
   }
   bool is_ntt_form() const { return parms_id_ != parms_id_zero; }
@@ -457,13 +507,29 @@ class Plaintext {
   const parms_id_type &parms_id() const { return parms_id_; }
   double &scale() { return scale_; }
   const double &scale() const { return scale_; }
-  std::uint64_t &operator[](std::size_t i) { return data_.at(i); }
-  const std::uint64_t &operator[](std::size_t i) const { return data_.at(i); }
+  std::uint64_t &operator[](std::size_t i) { return realize(), data_.at(i); }
+  const std::uint64_t &operator[](std::size_t i) const { return realize(), data_.at(i); }
+
+  // facade: element `index` of a device-resident batch (see facade::LazyPlain)
+  void facade_set_lazy(std::shared_ptr<const facade::LazyPlain> batch, std::size_t index) {
+    data_.clear(), parms_id_ = parms_id_zero, scale_ = 1.0;
+    lazy_ = std::move(batch), lazy_index_ = index;
+  }
+  const std::shared_ptr<const facade::LazyPlain> &facade_lazy() const { return lazy_; }
+  std::size_t facade_lazy_index() const { return lazy_index_; }
 
  private:
+  void realize() const {  // (not thread-safe on one object, like any first write)
+    if (!lazy_) return;
+    auto batch = std::move(lazy_);
+    lazy_.reset();
+    batch->materialize(lazy_index_, data_);
+  }
   parms_id_type parms_id_ = parms_id_zero;
   double scale_ = 1.0;
-  std::vector<std::uint64_t> data_;
+  mutable std::vector<std::uint64_t> data_;
+  mutable std::shared_ptr<const facade::LazyPlain> lazy_;
+  std::size_t lazy_index_ = 0;
 };
 
 class Ciphertext {
@@ -991,6 +1057,9 @@ class Decryptor {
 class Evaluator {
  public:
   explicit Evaluator(const SEALContext &context) : context_(context) {}
+  // facade: state a batched implementation of the protocol classes keeps with the evaluator it was given (stream,
+  // device copies of the keys, layer plans; openmm_amd/dropin) -- lives and dies with the object that owns the evaluator
+  std::shared_ptr<void> &facade_ext() const { return ext_; }
 
   void add_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const { plain_op(encrypted, plain, false); }
   void add_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const {
@@ -1106,6 +1175,7 @@ class Evaluator {
     ct.is_ntt_form() = !inverse;
   }
   SEALContext context_;
+  mutable std::shared_ptr<void> ext_;
 };
 
 // ------------------------------------------------------------------------------------------ BatchEncoder

@@ -424,6 +424,11 @@ extern "C" int mmh_memcpy_d2h(void *dst, const void *d_src, size_t bytes, void *
   MMH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return MMH_OK;
 }
+extern "C" int mmh_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream) {
+  MMH_REQUIRE((d_dst && d_src) || bytes == 0, MMH_ERR_NULL_POINTER);
+  MMH_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMH_OK;
+}
 extern "C" int mmh_memset(void *d_dst, int value, size_t bytes, void *stream) {
   MMH_REQUIRE(d_dst || bytes == 0, MMH_ERR_NULL_POINTER);
   MMH_HIP(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mmh_scratch_release": [],
     "mmh_memcpy_h2d": [_vp, _vp, _sz, _vp],
     "mmh_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "mmh_memcpy_d2d": [_vp, _vp, _sz, _vp],
     "mmh_memset": [_vp, _int, _sz, _vp],
     "mmh_stream_sync": [_vp],
     "mmh_ntt_forward": [_vp, _vp, _sz, _sz, _vp],
