@@ -542,26 +542,28 @@ class Ciphertext {
     if (!cd) throw std::invalid_argument("parms_id is not valid for encryption parameters");
     parms_id_ = parms_id;
     size_ = size;
-    seeded_ = false;
+    seeded_ = pending_ = false;
     n_ = cd->parms().poly_modulus_degree();
     l_ = cd->parms().coeff_modulus().size();
     data_.resize(size_ * n_ * l_, 0);
   }
-  void resize(std::size_t size) { size_ = size, seeded_ = false, data_.resize(size_ * n_ * l_, 0); }
+  void resize(std::size_t size) { expand_pending(), size_ = size, seeded_ = false, data_.resize(size_ * n_ * l_, 0); }
   void release() {
-    parms_id_ = parms_id_zero, is_ntt_form_ = seeded_ = false, size_ = n_ = l_ = 0, scale_ = 1.0;
+    parms_id_ = parms_id_zero, is_ntt_form_ = seeded_ = pending_ = false, size_ = n_ = l_ = 0, scale_ = 1.0;
     data_.clear(), data_.shrink_to_fit();
   }
   // (a writable view ends the seeded state: c1 may no longer be what the seed expands to)
-  std::uint64_t *data() { return seeded_ = false, data_.data(); }
-  const std::uint64_t *data() const { return data_.data(); }
+  std::uint64_t *data() { return expand_pending(), seeded_ = false, data_.data(); }
+  const std::uint64_t *data() const { return expand_pending(), data_.data(); }
   std::uint64_t *data(std::size_t k) {
     if (k >= size_) throw std::out_of_range("poly_index must be within [0, size)");
+    expand_pending();
     seeded_ = false;
     return data_.data() + k * n_ * l_;
   }
   const std::uint64_t *data(std::size_t k) const {
     if (k >= size_) throw std::out_of_range("poly_index must be within [0, size)");
+    expand_pending();
     return data_.data() + k * n_ * l_;
   }
   std::size_t size() const { return size_; }
@@ -574,6 +576,7 @@ class Ciphertext {
   double &scale() { return scale_; }
   const double &scale() const { return scale_; }
   bool is_transparent() const {
+    expand_pending();
     return size_ < 2 || std::all_of(data_.begin() + n_ * l_, data_.end(), [](std::uint64_t c) { return c == 0; });
   }
 
@@ -581,6 +584,7 @@ class Ciphertext {
   // came out of encrypt_symmetric as a Serializable carries the seed of its c1 and is written in the seeded form
   // (c0 + UniformRandomGeneratorInfo): half the bytes, and the loader regenerates c1 with SEAL's Blake2xb expansion.
   std::streamoff save(std::ostream &os) const {
+    expand_pending();
     wire::CtMeta m;
     m.parms_id = parms_id_, m.is_ntt_form = is_ntt_form_, m.size = size_, m.poly_modulus_degree = n_;
     m.coeff_modulus_size = l_, m.scale = scale_;
@@ -609,12 +613,16 @@ class Ciphertext {
     if (n_ != m.poly_modulus_degree || l_ != m.coeff_modulus_size) throw std::logic_error("ciphertext data is invalid");
     is_ntt_form_ = m.is_ntt_form, scale_ = m.scale;
     data_ = std::move(words);
-    seeded_ = false;
-    if (seeded) {  // Ciphertext::expand_seed
-      std::vector<std::uint64_t> q;
-      for (const auto &mod : cd->parms().coeff_modulus()) q.push_back(mod.value());
-      wire::Blake2xbPRNG prng(seed);
-      wire::sample_poly_uniform(prng, q, n_, data(1));
+    seeded_ = pending_ = false;
+    if (seeded) {
+      // Ciphertext::expand_seed, deferred: c1 is regenerated from the seed the first time somebody looks at the data
+      // (SEAL expands inside load).  cheetah-api.cpp loads a layer's ciphertexts one by one on one thread
+      // (:710-737); the batched protocol classes expand all of them side by side (facade_expand_now from worker
+      // threads) before they upload -- same polynomial either way.
+      pending_q_.clear();
+      for (const auto &mod : cd->parms().coeff_modulus()) pending_q_.push_back(mod.value());
+      std::memcpy(seed_.data(), seed, wire::kSeedBytes);
+      pending_ = true;
     }
     return (std::streamoff)total;
   }
@@ -622,9 +630,11 @@ class Ciphertext {
     const std::streamoff n = unsafe_load(context, is);
     auto cd = context.get_context_data(parms_id_);
     const auto &q = cd->parms().coeff_modulus();
-    for (std::size_t k = 0; k < size_; ++k)  // is_valid_for: every coefficient below its modulus
+    // is_valid_for: every coefficient below its modulus (a polynomial still to be expanded from its seed is reduced
+    // by construction)
+    for (std::size_t k = 0; k < (pending_ ? 1 : size_); ++k)
       for (std::size_t l = 0; l < l_; ++l) {
-        const std::uint64_t *p = data(k) + l * n_, m = q[l].value();
+        const std::uint64_t *p = data_.data() + (k * l_ + l) * n_, m = q[l].value();
         if (std::any_of(p, p + n_, [m](std::uint64_t c) { return c >= m; }))
           throw std::logic_error("ciphertext data is invalid");
       }
@@ -633,14 +643,28 @@ class Ciphertext {
   // facade: the seed c1 was expanded from (set by Encryptor::encrypt_symmetric's Serializable form)
   void facade_set_seed(const std::uint8_t (&seed)[wire::kSeedBytes]) { std::memcpy(seed_.data(), seed, wire::kSeedBytes), seeded_ = true; }
   bool facade_seeded() const { return seeded_; }
+  // facade: a loaded seeded ciphertext whose c1 has not been expanded yet; facade_expand_now does it (safe to call
+  // for different objects from different threads)
+  bool facade_pending() const { return pending_; }
+  void facade_expand_now() const { expand_pending(); }
 
  private:
+  void expand_pending() const {
+    if (!pending_) return;
+    std::uint8_t seed[wire::kSeedBytes];
+    std::memcpy(seed, seed_.data(), sizeof(seed));
+    wire::Blake2xbPRNG prng(seed);
+    wire::sample_poly_uniform(prng, pending_q_, n_, data_.data() + n_ * l_);
+    pending_ = false;
+  }
   parms_id_type parms_id_ = parms_id_zero;
   bool is_ntt_form_ = false, seeded_ = false;
+  mutable bool pending_ = false;
+  std::vector<std::uint64_t> pending_q_;
   std::array<std::uint8_t, wire::kSeedBytes> seed_{};
   std::size_t size_ = 0, n_ = 0, l_ = 0;
   double scale_ = 1.0;
-  std::vector<std::uint64_t> data_;
+  mutable std::vector<std::uint64_t> data_;
 };
 
 // SEAL's Serializable<T> defers seed expansion to save(); here it simply owns the object

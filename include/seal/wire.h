@@ -69,13 +69,23 @@ class Blake2b {
     for (int i = 0; i < 8; ++i) store64(full + 8 * i, h_[i]);
     std::memcpy(out, full, outlen_);
   }
-  static std::uint64_t load64(const std::uint8_t *p) {
+  static std::uint64_t load64(const std::uint8_t *p) {  // little-endian word
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+    std::uint64_t v;
+    std::memcpy(&v, p, 8);
+    return v;
+#else
     std::uint64_t v = 0;
     for (int i = 7; i >= 0; --i) v = (v << 8) | p[i];
     return v;
+#endif
   }
   static void store64(std::uint8_t *p, std::uint64_t v) {
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+    std::memcpy(p, &v, 8);
+#else
     for (int i = 0; i < 8; ++i) p[i] = (std::uint8_t)(v >> (8 * i));
+#endif
   }
 
  private:
@@ -85,13 +95,6 @@ class Blake2b {
     if (t_[0] < n) ++t_[1];
   }
   void compress(bool last) {
-    static const std::uint8_t S[12][16] = {
-        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
-        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
-        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
-        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
-        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
-        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
     static const std::uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull,
                                         0xa54ff53a5f1d36f1ull, 0x510e527fade682d1ull, 0x9b05688c2b3e6c1full,
                                         0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
@@ -100,20 +103,34 @@ class Blake2b {
     for (int i = 0; i < 8; ++i) v[i] = h_[i], v[i + 8] = IV[i];
     v[12] ^= t_[0], v[13] ^= t_[1];
     if (last) v[14] = ~v[14];
-    auto G = [&](int r, int i, int a, int b, int c, int d) {
-      v[a] = v[a] + v[b] + m[S[r][2 * i]];
-      v[d] = rotr(v[d] ^ v[a], 32);
-      v[c] = v[c] + v[d];
-      v[b] = rotr(v[b] ^ v[c], 24);
-      v[a] = v[a] + v[b] + m[S[r][2 * i + 1]];
-      v[d] = rotr(v[d] ^ v[a], 16);
-      v[c] = v[c] + v[d];
-      v[b] = rotr(v[b] ^ v[c], 63);
-    };
-    for (int r = 0; r < 12; ++r) {
-      G(r, 0, 0, 4, 8, 12), G(r, 1, 1, 5, 9, 13), G(r, 2, 2, 6, 10, 14), G(r, 3, 3, 7, 11, 15);
-      G(r, 4, 0, 5, 10, 15), G(r, 5, 1, 6, 11, 12), G(r, 6, 2, 7, 8, 13), G(r, 7, 3, 4, 9, 14);
-    }
+    // (the message schedule as compile-time constants: the twelve rounds unroll into straight-line code, which is
+    // what the seed expansion of every fresh ciphertext spends its time in)
+#define MM_B2_G(a, b, c, d, x, y)     \
+  v[a] = v[a] + v[b] + m[x];          \
+  v[d] = rotr(v[d] ^ v[a], 32);       \
+  v[c] = v[c] + v[d];                 \
+  v[b] = rotr(v[b] ^ v[c], 24);       \
+  v[a] = v[a] + v[b] + m[y];          \
+  v[d] = rotr(v[d] ^ v[a], 16);       \
+  v[c] = v[c] + v[d];                 \
+  v[b] = rotr(v[b] ^ v[c], 63);
+#define MM_B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+  MM_B2_G(0, 4, 8, 12, s0, s1) MM_B2_G(1, 5, 9, 13, s2, s3) MM_B2_G(2, 6, 10, 14, s4, s5) MM_B2_G(3, 7, 11, 15, s6, s7) \
+  MM_B2_G(0, 5, 10, 15, s8, s9) MM_B2_G(1, 6, 11, 12, s10, s11) MM_B2_G(2, 7, 8, 13, s12, s13) MM_B2_G(3, 4, 9, 14, s14, s15)
+    MM_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    MM_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    MM_B2_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    MM_B2_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    MM_B2_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    MM_B2_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    MM_B2_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    MM_B2_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    MM_B2_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    MM_B2_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    MM_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    MM_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+#undef MM_B2_ROUND
+#undef MM_B2_G
     for (int i = 0; i < 8; ++i) h_[i] ^= v[i] ^ v[i + 8];
   }
   std::uint64_t h_[8], t_[2] = {0, 0};
@@ -252,6 +269,13 @@ struct Writer {
     Blake2b::store64(b, v);
     raw(b, 8);
   }
+  void words(const std::uint64_t *v, std::size_t n) {  // n little-endian words
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+    raw(v, n * 8);
+#else
+    for (std::size_t i = 0; i < n; ++i) u64(v[i]);
+#endif
+  }
   void header(std::uint64_t total) { u16(kMagic), u8(0x10), u8(3), u8(7), u8(compr_none), u16(0), u64(total); }
 };
 struct Reader {
@@ -326,7 +350,7 @@ inline std::string save_ciphertext(const CtMeta &m, const std::uint64_t *data, c
   w.u64(scale_bits);
   w.header(array_bytes);
   w.u64(words);
-  for (std::size_t i = 0; i < words; ++i) w.u64(data[i]);
+  w.words(data, words);
   if (seed) {
     w.header(kPrngInfoBytes);
     w.u8(prng_blake2xb);
@@ -373,7 +397,12 @@ inline std::size_t load_ciphertext(const std::uint8_t *bytes, std::size_t n, CtM
   seeded = words == per_poly && m.size == 2;
   if (!seeded && words != total) throw std::logic_error("seal wire: ciphertext data has the wrong length");
   data.assign(total, 0);
+  r.need(words * 8);
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+  std::memcpy(data.data(), r.p, words * 8), r.p += words * 8;
+#else
   for (std::size_t i = 0; i < words; ++i) data[i] = r.u64();
+#endif
   if (seeded) {
     const std::size_t info_body = r.header();
     if (info_body != 1 + kSeedBytes) throw std::logic_error("seal wire: UniformRandomGeneratorInfo size mismatch");

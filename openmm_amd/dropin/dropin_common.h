@@ -8,6 +8,9 @@
 #include <seal/seal.h>
 
 #include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -32,6 +35,24 @@ using ::Code;  // (the reference declares it at global scope, include/gemini/cor
   do {                        \
     if (!(cond)) return code; \
   } while (0)
+
+// MM_DROPIN_TRACE=1: wall time of every method of the batched classes on stderr (where a layer call's host-to-host time
+// goes: seed expansion, copies into and out of the seal:: objects, the device call)
+struct Trace {
+  const char *what;
+  std::chrono::steady_clock::time_point t0;
+  static bool on() {
+    static const bool v = std::getenv("MM_DROPIN_TRACE") != nullptr;
+    return v;
+  }
+  explicit Trace(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char *step) {
+    if (!on()) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[dropin] %s / %s: %.3f ms\n", what, step, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 // Device buffers recycled by size (hipMalloc / hipFree cost 0.1-0.3 ms each and a layer call needs a dozen).  All work
 // of one Fast object runs on its one stream, which orders a buffer's next use after its last.
@@ -231,10 +252,13 @@ inline const PlainBatch *whole_batch(const seal::Plaintext *v, std::size_t n, in
 // host ciphertexts (the vectors of `parts`, one after the other) -> one device array [n][2][limbs][N]; every
 // ciphertext must have two polynomials of `limbs` limbs in coefficient form
 inline Code upload_cts(Fast &f, std::initializer_list<const std::vector<seal::Ciphertext> *> parts, std::size_t limbs,
-                       Dev &out) {
+                       Dev &out, std::size_t nthreads = 4) {
   const std::size_t words = 2 * limbs * f.N;
   std::size_t n = 0;
   for (const auto *v : parts) {
+    // fresh ciphertexts arrive with c1 as a seed (Ciphertext::load leaves it so): expand them side by side
+    if (!v->empty() && (*v)[0].facade_pending())
+      parallel_for(v->size(), nthreads, [&](std::size_t i) { (*v)[i].facade_expand_now(); });
     n += v->size();
     for (const auto &c : *v)
       DI_ENSURE(c.size() == 2 && c.coeff_modulus_size() == limbs && c.poly_modulus_degree() == f.N && !c.is_ntt_form(),
@@ -253,8 +277,9 @@ inline Code upload_cts(Fast &f, std::initializer_list<const std::vector<seal::Ci
   DI_TRY(f.up(out, host, n * words));
   return Code::OK;
 }
-inline Code upload_cts(Fast &f, const std::vector<seal::Ciphertext> &cts, std::size_t limbs, Dev &out) {
-  return upload_cts(f, {&cts}, limbs, out);
+inline Code upload_cts(Fast &f, const std::vector<seal::Ciphertext> &cts, std::size_t limbs, Dev &out,
+                       std::size_t nthreads = 4) {
+  return upload_cts(f, {&cts}, limbs, out, nthreads);
 }
 // device array [n][2][1][N] at the last level -> host ciphertexts (enqueue + wait)
 inline Code download_last_level(Fast &f, const seal::SEALContext &context, const Dev &d, std::size_t n,

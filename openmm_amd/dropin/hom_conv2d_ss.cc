@@ -107,6 +107,7 @@ Code HomConv2DSS::encryptImage(const Tensor<uint64_t> &img, const Meta &meta,
   ENSURE_OR_RETURN(context_ && encryptor_ && f && f->sk, Code::ERR_CONFIG);
   ENSURE_OR_RETURN(img.shape().IsSameSize(meta.ishape), Code::ERR_DIM_MISMATCH);
   std::lock_guard<std::recursive_mutex> g(f->mu);
+  Trace tr("encryptImage");
   PlanInfo pi;
   CHECK_ERR(plan_for(*f, meta, pi), "encryptImage");
   const size_t N = f->N, L = f->L, words = (size_t)img.NumElements();
@@ -114,12 +115,16 @@ Code HomConv2DSS::encryptImage(const Tensor<uint64_t> &img, const Meta &meta,
   ENSURE_OR_RETURN(d_img && e && cts, Code::ERR_SEAL_MEMORY);
   DI_TRY(f->up(d_img, img.data(), words));
   std::vector<std::array<std::uint8_t, seal::wire::kSeedBytes>> seeds;
+  tr.lap("plan + upload");
   CHECK_ERR(fresh_a(*f, *context_, pi.n_in, nthreads, a, seeds), "encryptImage");
+  tr.lap("seed expansion");
   std::uint32_t key[8];
   const std::uint64_t sid = f->streams(key, 1);
   DI_TRY(mmh_sample_noise(key, sid, (std::int64_t *)e.p, pi.n_in * N, f->stream));
   DI_TRY(mmh_conv_encrypt_image(pi.plan, f->sk.p, d_img.p, a.p, (const std::int64_t *)e.p, cts.p, f->stream));
-  return download_fresh(*f, *context_, cts, pi.n_in, seeds, encrypted_img);
+  const Code c = download_fresh(*f, *context_, cts, pi.n_in, seeds, encrypted_img);
+  tr.lap("encrypt + download");
+  return c;
 }
 
 // :524-535: the server's share stays on the device as the raw tensor; the plaintexts the reference builds here exist
@@ -160,6 +165,7 @@ Code HomConv2DSS::encodeFilters(const std::vector<Tensor<uint64_t>> &filters, co
   ConvFast *f = fast_of(evaluator_);
   ENSURE_OR_RETURN(context_ && f, Code::ERR_CONFIG);
   std::lock_guard<std::recursive_mutex> g(f->mu);
+  Trace tr("encodeFilters");
   PlanInfo pi;
   CHECK_ERR(plan_for(*f, meta, pi), "EncodeFilter");
   const size_t fw = (size_t)meta.fshape.num_elements(), per_ch = (size_t)(meta.fshape.height() * meta.fshape.width());
@@ -192,9 +198,11 @@ Code HomConv2DSS::encodeFilters(const std::vector<Tensor<uint64_t>> &filters, co
     if (!b.pts) return (int)MMH_ERR_MEMORY;
     return mmh_conv_encode_filters(plan, b.raw.p, b.pts.p, b.fast->stream);
   };
+  tr.lap("upload + zero scan");
   encoded_filters.assign(M, std::vector<seal::Plaintext>(pi.n_cs));
   for (size_t m = 0; m < M; ++m)
     for (size_t c = 0; c < pi.n_cs; ++c) encoded_filters[m][c].facade_set_lazy(batch, m * pi.n_cs + c);
+  tr.lap("plaintext objects");
   return Code::OK;
 }
 
@@ -216,6 +224,7 @@ Code HomConv2DSS::conv2DSS(const std::vector<seal::Ciphertext> &img_share0, cons
   ConvFast *f = fast_of(evaluator_);
   ENSURE_OR_RETURN(context_ && f && f->pk_last, Code::ERR_CONFIG);
   std::lock_guard<std::recursive_mutex> g(f->mu);
+  Trace tr("conv2DSS");
   PlanInfo pi;
   if (plan_for(*f, meta, pi) != Code::OK) {
     LOG(WARNING) << "conv2DSS: empty out_shape";
@@ -249,6 +258,7 @@ Code HomConv2DSS::conv2DSS(const std::vector<seal::Ciphertext> &img_share0, cons
       return c == Code::ERR_INVALID_ARG ? Code::ERR_INTERNAL : c;  // add_plain / multiply_plain would throw (:659-662)
     }
   }
+  tr.lap("checks + upload");
   const size_t out_words = (size_t)(pi.oshape[0] * pi.oshape[1] * pi.oshape[2]);
   Dev u = f->mk(pi.n_out * N), e1 = f->mk(pi.n_out * N), mask = f->mk(pi.n_out * N), out_cts = f->mk(pi.n_out * 2 * N);
   Dev share = f->mk(out_words);
@@ -321,7 +331,10 @@ Code HomConv2DSS::conv2DSS(const std::vector<seal::Ciphertext> &img_share0, cons
   const TensorShape oshape({pi.oshape[0], pi.oshape[1], pi.oshape[2]});
   out_share1.Reshape(oshape);  // :694
   DI_TRY(f->down(out_share1.data(), share, out_words));
-  return download_last_level(*f, *context_, out_cts, pi.n_out, out_share0);
+  tr.lap("enqueue");
+  const Code c = download_last_level(*f, *context_, out_cts, pi.n_out, out_share0);
+  tr.lap("device + download");
+  return c;
 }
 
 // :853-941: decrypt + gather (the ciphertexts arrive through unsafe_load: truncated, so "invalid" to SEAL)
@@ -330,6 +343,7 @@ Code HomConv2DSS::decryptToTensor(const std::vector<seal::Ciphertext> &enc_tenso
   ConvFast *f = fast_of(evaluator_);
   ENSURE_OR_RETURN(context_ && sk_ && f && f->sk_last, Code::ERR_CONFIG);
   std::lock_guard<std::recursive_mutex> g(f->mu);
+  Trace tr("decryptToTensor");
   PlanInfo pi;
   ENSURE_OR_RETURN(plan_for(*f, meta, pi) == Code::OK, Code::ERR_INVALID_ARG);
   ENSURE_OR_RETURN(enc_tensor.size() == pi.n_out, Code::ERR_INVALID_ARG);
@@ -343,6 +357,7 @@ Code HomConv2DSS::decryptToTensor(const std::vector<seal::Ciphertext> &enc_tenso
   out.Reshape(TensorShape({pi.oshape[0], pi.oshape[1], pi.oshape[2]}));
   DI_TRY(f->down(out.data(), res, out_words));
   DI_TRY(f->sync());
+  tr.lap("all");
   return Code::OK;
 }
 
