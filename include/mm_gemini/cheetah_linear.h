@@ -26,7 +26,20 @@ class CheetahLinear {
   using BNMeta = HomBNSS::Meta;
 
   // party: 1 = ALICE (server, model owner), 2 = BOB (client, key owner)  -- sci::ALICE / sci::BOB
+  // With MM_GEMINI_DEVICES="0,1,..." in the environment this constructor takes that device list instead of `device`.
   CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, size_t nthreads = 1, int device = 0);
+  struct Options {
+    size_t nthreads = 1;            // as the reference's argument; the devices do the work
+    // devices[0] holds the keys and does all of BOB's work.  ALICE cuts the server side of conv2d / conv2d_nhwc (output
+    // filters), fc / fc_in_out (row blocks) and bn (ciphertexts) over all of them, in LaunchWorks' ranges
+    // (hom_conv2d_ss.cc:597-607); the bytes on the wire do not depend on the list.  A device may be listed twice.
+    // BOLE and bn_direct run on devices[0].
+    std::vector<int> devices{0};
+    // 8 words; when set, all of the object's randomness (sampler streams and ciphertext seeds) follows from it
+    // instead of the OS.  For tests that compare runs; never in production.
+    const uint32_t *sampler_key = nullptr;
+  };
+  CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, const Options &options);
   ~CheetahLinear();
   CheetahLinear(const CheetahLinear &) = delete;
 
@@ -41,6 +54,7 @@ class CheetahLinear {
                    uint64_t *out_nhwc, int64_t expect_oh = 0, int64_t expect_ow = 0) const;
   // idle device buffers of this object back to the driver (it keeps a size-keyed pool, capped at 2 GiB idle)
   void release_device_buffers() const;
+  size_t n_devices() const;  // ALICE: the devices that share a layer; BOB: 1
   void fc(const Tensor<uint64_t> &input_vector, const Tensor<uint64_t> &weight_matrix, const FCMeta &meta,
           Tensor<uint64_t> &out_vec_share) const;
   // the same with the weights as the layer adapter holds them: [meta.weight_shape.cols()][meta.weight_shape.rows()]

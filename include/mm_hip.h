@@ -258,6 +258,11 @@ int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key[8], uint64
  * calls (tests/test_sampler_gpu.py).  The caller advances its stream id by 3. */
 int mmh_sample_reshare(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t n, int64_t *d_u,
                        int64_t *d_e1, uint64_t *d_mask, void *stream);
+/* Polynomials [first_poly, first_poly + n) of the same draw, each array [n][N]: the rows mmh_sample_reshare would
+ * write at first_poly ...  A layer cut over several devices (LaunchWorks' ranges of output ciphertexts,
+ * hom_conv2d_ss.cc:597-607) draws each range where it is used and puts the bytes of the one-device run on the wire. */
+int mmh_sample_reshare_range(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t first_poly, size_t n,
+                             int64_t *d_u, int64_t *d_e1, uint64_t *d_mask, void *stream);
 /* signed small polynomials [n][N] -> RNS + forward NTT [n][limbs][N]: secret key to NTT form
  * (seal::KeyGenerator, cheetah-api.cpp:109-111) */
 int mmh_signed_to_ntt(const mmh_ctx *ctx, int lv, const int64_t *d_signed, size_t n, uint64_t *d_out,
@@ -425,6 +430,10 @@ typedef struct mmh_fc_meta {
 } mmh_fc_meta;
 typedef struct mmh_fc_plan mmh_fc_plan;
 int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan **out);
+/* The same with (d0, d1) given instead of taken from getSplit: the plan of the row blocks [b0, b1) of a larger
+ * matrix, whose split the sub-matrix (rows = those blocks' rows) has to keep (matVecMul's workers each take a range of
+ * row blocks, hom_fc_ss.cc:443-457).  1 <= d0, d1 and d0 * d1 <= N. */
+int mmh_fc_plan_create_split(const mmh_ctx *ctx, const mmh_fc_meta *meta, const int64_t split[2], mmh_fc_plan **out);
 int mmh_fc_plan_destroy(mmh_fc_plan *plan);
 /* split = getSplit's (d0, d1) (hom_fc_ss.cc:25-50); n_in = ceil(cols/d1), n_out = ceil(rows/d0) */
 int mmh_fc_plan_info(const mmh_fc_plan *plan, int64_t split[2], size_t *n_in_cts, size_t *n_out_cts);

@@ -162,17 +162,19 @@ extern "C" int mmh_fc_plan_destroy(mmh_fc_plan *p) {
   return MMH_OK;
 }
 
-extern "C" int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan **out) {
+static int fc_plan_make(const mmh_ctx *ctx, const mmh_fc_meta *meta, const int64_t *split, mmh_fc_plan **out) {
   MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && meta && out, MMH_ERR_NULL_POINTER);
   *out = nullptr;
   MMH_REQUIRE(ctx->t >= 2, MMH_ERR_CONFIG);
   MMH_REQUIRE(meta->rows > 0 && meta->cols > 0, MMH_ERR_INVALID_ARG);
+  const long N = (long)ctx->N;
+  MMH_REQUIRE(!split || (split[0] >= 1 && split[1] >= 1 && split[0] * split[1] <= N), MMH_ERR_INVALID_ARG);
   mmh_fc_plan *p = new mmh_fc_plan();
   p->ctx = ctx;
   p->meta = *meta;
-  const long N = (long)ctx->N;
-  fc_split(meta->rows, meta->cols, N, p->d0, p->d1);
+  if (split) p->d0 = (long)split[0], p->d1 = (long)split[1];
+  else fc_split(meta->rows, meta->cols, N, p->d0, p->d1);
   p->n_in = (size_t)((meta->cols + p->d1 - 1) / p->d1);
   p->n_out = (size_t)((meta->rows + p->d0 - 1) / p->d0);
   // addRandomMask targets i*d1 (hom_fc_ss.cc:482-485, :504-510); removeUnusedCoeffs keeps
@@ -197,6 +199,14 @@ extern "C" int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, m
   }
   *out = p;
   return MMH_OK;
+}
+extern "C" int mmh_fc_plan_create(const mmh_ctx *ctx, const mmh_fc_meta *meta, mmh_fc_plan **out) {
+  return fc_plan_make(ctx, meta, nullptr, out);
+}
+extern "C" int mmh_fc_plan_create_split(const mmh_ctx *ctx, const mmh_fc_meta *meta, const int64_t split[2],
+                                        mmh_fc_plan **out) {
+  MMH_REQUIRE(split, MMH_ERR_NULL_POINTER);
+  return fc_plan_make(ctx, meta, split, out);
 }
 
 extern "C" int mmh_fc_split(int64_t rows, int64_t cols, size_t N, int64_t split[2]) {

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void sample_raw_kernel(ChaChaKey key, u64 stre
 // 64 consecutive words.  The fused launch below and the stand-alone entry points share these functions, hence agree.
 constexpr int kTernaryPerBlock = 16, kNoisePerBlock = 12, kUniformPerBlock = 8;
 
+// `tile` is the tile's index in the whole stream; of its samples those with index in [first, first + n) are stored, at
+// out[index - first] (a range of a longer draw equals that part of the whole draw: the host's device shards use it)
 __device__ __forceinline__ void ternary_block(const ChaChaKey &key, u64 sid, u64 counter0, size_t tile, int t,
-                                              int64_t *out, size_t n) {
+                                              int64_t *out, size_t n, size_t first = 0) {
   u64 w[8];
   chacha20_block(key, sid, counter0 + tile * 256 + t, w);
   const size_t base = tile * (256 * kTernaryPerBlock) + t;
@@ -69,11 +71,11 @@ __device__ __forceinline__ void ternary_block(const ChaChaKey &key, u64 sid, u64
   for (int j = 0; j < kTernaryPerBlock; ++j) {
     const u32 r = (u32)(w[j >> 1] >> ((j & 1) * 32));
     const size_t idx = base + (size_t)j * 256;
-    if (idx < n) out[idx] = (int64_t)__umulhi(r, 3u) - 1;
+    if (idx - first < n) out[idx - first] = (int64_t)__umulhi(r, 3u) - 1;   // (unsigned: idx < first wraps above n)
   }
 }
 __device__ __forceinline__ void noise_block(const ChaChaKey &key, u64 sid, u64 counter0, size_t tile, int t,
-                                            int64_t *out, size_t n) {
+                                            int64_t *out, size_t n, size_t first = 0) {
   u64 w[8];
   chacha20_block(key, sid, counter0 + tile * 256 + t, w);
   const size_t base = tile * (256 * kNoisePerBlock) + t;
@@ -83,18 +85,19 @@ __device__ __forceinline__ void noise_block(const ChaChaKey &key, u64 sid, u64 c
     u64 v = w[a] >> sh;
     if (sh > 22) v |= w[a + 1] << (64 - sh);   // (a + 1 <= 7: 42 * 12 = 504 bits)
     const size_t idx = base + (size_t)j * 256;
-    if (idx < n) out[idx] = (int64_t)__popcll(v & 0x1FFFFF) - (int64_t)__popcll((v >> 21) & 0x1FFFFF);
+    if (idx - first < n) out[idx - first] = (int64_t)__popcll(v & 0x1FFFFF) - (int64_t)__popcll((v >> 21) & 0x1FFFFF);
   }
 }
 __device__ __forceinline__ void uniform_block(const ChaChaKey &key, u64 sid, u64 counter0, size_t tile, int t, u64 *out,
-                                              size_t n, int logN, int limbs, const DevMod *__restrict__ mods) {
+                                              size_t n, int logN, int limbs, const DevMod *__restrict__ mods,
+                                              size_t first = 0) {
   u64 w[8];
   chacha20_block(key, sid, counter0 + tile * 256 + t, w);
   const size_t base = tile * (256 * kUniformPerBlock) + t;
 #pragma unroll
   for (int j = 0; j < kUniformPerBlock; ++j) {
     const size_t idx = base + (size_t)j * 256;
-    if (idx >= n) continue;
+    if (idx - first >= n) continue;
     const DevMod &q = mods[(idx >> logN) % limbs];
     u64 v;
     if (w[j] < q.q * q.barrett_hi) {   // barrett_hi = floor(2^64 / q): below the largest multiple of q
@@ -104,7 +107,7 @@ __device__ __forceinline__ void uniform_block(const ChaChaKey &key, u64 sid, u64
       chacha20_block(key, sid, (u64(1) << 63) | idx, x);
       v = csub(barrett128(reduce64(x[1], q), x[0], q.q, q.barrett_hi, q.barrett_lo), q.q);
     }
-    out[idx] = v;
+    out[idx - first] = v;
   }
 }
 
@@ -124,14 +127,22 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(ChaChaKey key, u64 
 }
 
 // the randomness of n re-sharings in one launch: u = ternary(stream_id), e1 = noise(stream_id + 1), mask =
-// uniform at the last level (stream_id + 2), n polynomials of N coefficients each
+// uniform at the last level (stream_id + 2), n polynomials of N coefficients each: coefficients [first, first + total)
+// of the three streams
+struct ReshareTiles {
+  unsigned count_u, count_e;    // blocks [0, count_u) draw u, the next count_e draw e1, the rest the mask
+  unsigned lo_u, lo_e, lo_m;    // the streams' first tiles that meet the range
+};
 __global__ __launch_bounds__(256) void sample_reshare_kernel(ChaChaKey key, u64 stream_id, int64_t *u, int64_t *e1,
-                                                             u64 *mask, size_t total, int logN, unsigned tiles_u,
-                                                             unsigned tiles_e, const DevMod *__restrict__ mods) {
+                                                             u64 *mask, size_t first, size_t total, int logN,
+                                                             ReshareTiles tl, const DevMod *__restrict__ mods) {
   const unsigned b = blockIdx.x;
-  if (b < tiles_u) ternary_block(key, stream_id, 0, b, threadIdx.x, u, total);
-  else if (b < tiles_u + tiles_e) noise_block(key, stream_id + 1, 0, b - tiles_u, threadIdx.x, e1, total);
-  else uniform_block(key, stream_id + 2, 0, b - tiles_u - tiles_e, threadIdx.x, mask, total, logN, 1, mods);
+  if (b < tl.count_u) ternary_block(key, stream_id, 0, tl.lo_u + b, threadIdx.x, u, total, first);
+  else if (b < tl.count_u + tl.count_e)
+    noise_block(key, stream_id + 1, 0, tl.lo_e + (b - tl.count_u), threadIdx.x, e1, total, first);
+  else
+    uniform_block(key, stream_id + 2, 0, tl.lo_m + (b - tl.count_u - tl.count_e), threadIdx.x, mask, total, logN, 1, mods,
+                  first);
 }
 
 __global__ __launch_bounds__(256) void signed_to_rns_kernel2(const int64_t *__restrict__ v, u64 *__restrict__ out,
@@ -201,20 +212,26 @@ extern "C" int mmh_sample_uniform(const mmh_ctx *ctx, int lv, const uint32_t key
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }
-extern "C" int mmh_sample_reshare(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t n, int64_t *d_u,
-                                  int64_t *d_e1, uint64_t *d_mask, void *stream) {
+extern "C" int mmh_sample_reshare_range(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t first_poly,
+                                        size_t n, int64_t *d_u, int64_t *d_e1, uint64_t *d_mask, void *stream) {
   MMH_DEVICE_SCOPE(ctx);
   MMH_REQUIRE(ctx && key && (n == 0 || (d_u && d_e1 && d_mask)), MMH_ERR_NULL_POINTER);
   if (n == 0) return MMH_OK;
   ChaChaKey k;
   for (int i = 0; i < 8; ++i) k.k[i] = key[i];
-  const size_t total = n * ctx->N;
-  const unsigned tu = tiles_of(total, kTernaryPerBlock), te = tiles_of(total, kNoisePerBlock),
-                 tm = tiles_of(total, kUniformPerBlock);
-  hipLaunchKernelGGL(sample_reshare_kernel, dim3(tu + te + tm), dim3(256), 0, (hipStream_t)stream, k, stream_id, d_u,
-                     d_e1, d_mask, total, ctx->logN, tu, te, ctx->d_mods);
+  const size_t first = first_poly * ctx->N, total = n * ctx->N;
+  auto lo = [&](int per) { return (unsigned)(first / (256 * (size_t)per)); };
+  auto count = [&](int per) { return tiles_of(first + total, per) - lo(per); };
+  ReshareTiles tl{count(kTernaryPerBlock), count(kNoisePerBlock), lo(kTernaryPerBlock), lo(kNoisePerBlock),
+                  lo(kUniformPerBlock)};
+  hipLaunchKernelGGL(sample_reshare_kernel, dim3(tl.count_u + tl.count_e + count(kUniformPerBlock)), dim3(256), 0,
+                     (hipStream_t)stream, k, stream_id, d_u, d_e1, d_mask, first, total, ctx->logN, tl, ctx->d_mods);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
+}
+extern "C" int mmh_sample_reshare(const mmh_ctx *ctx, const uint32_t key[8], uint64_t stream_id, size_t n, int64_t *d_u,
+                                  int64_t *d_e1, uint64_t *d_mask, void *stream) {
+  return mmh_sample_reshare_range(ctx, key, stream_id, 0, n, d_u, d_e1, d_mask, stream);
 }
 extern "C" int mmh_signed_to_ntt(const mmh_ctx *ctx, int lv, const int64_t *d_signed, size_t n, uint64_t *d_out,
                                  void *stream) {

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <array>
 #include <functional>
 #include <iterator>
@@ -132,31 +134,31 @@ struct DeviceGuard {
     if (switched) (void)mmh_set_device(prev);
   }
 };
-}  // namespace
 
-struct CheetahLinear::Impl {
+// One device's working set: its stream and buffer pool, the two BFV contexts with the key material that device
+// needs, and the layer plans made on it.  The object's first device does all of BOB's work and all of ALICE's when
+// there is one device; ALICE's further devices each take a range of a layer's output ciphertexts (conv_team /
+// fc_team / bn_team below).
+struct Worker {
   static constexpr size_t N = 4096, L = 2;
   int device = 0;
-  void *stream = nullptr;  // every copy and kernel of this object; one wait before bytes go to the channel
+  void *stream = nullptr;  // every copy and kernel of this device; one wait before bytes go to the channel
   mutable DevPool pool;
   Keys ring, field;
-  uint32_t key[8];
-  mutable uint64_t stream_id = 1;
-  mm::IOChannel *io = nullptr;
 
   // layer geometry is computed once per shape (the reference redoes it on every call)
   mutable std::mutex plan_mu;
   mutable std::map<std::array<int64_t, 9>, mmh_conv_plan *> conv_plans;
-  mutable std::map<std::array<int64_t, 3>, mmh_fc_plan *> fc_plans;
+  mutable std::map<std::array<int64_t, 5>, mmh_fc_plan *> fc_plans;
 
-  ~Impl() {
+  Worker() = default;
+  Worker(const Worker &) = delete;
+  ~Worker() {
     if (stream) (void)mmh_stream_sync(stream);
     for (auto &kv : conv_plans) mmh_conv_plan_destroy(kv.second);
     for (auto &kv : fc_plans) mmh_fc_plan_destroy(kv.second);
     mmh_ctx_destroy(ring.ctx);
     mmh_ctx_destroy(field.ctx);
-    if (staging.p) mmh_host_free(staging.p);
-    if (flag_host) mmh_host_free(flag_host);
     mmh_stream_destroy(stream);
   }  // the key buffers return to the pool and the pool frees its blocks as the members go (hipFree needs no stream)
   Dev mk(size_t words) const { return Dev(&pool, words); }
@@ -178,14 +180,32 @@ struct CheetahLinear::Impl {
     must(mmh_conv_plan_create(ring.ctx, &m, &plan), "CheetahLinear::conv2d shape inference");
     return conv_plans[key] = plan;
   }
-  mmh_fc_plan *fc_plan(const mmh_fc_meta &m) const {
-    const std::array<int64_t, 3> key{m.rows, m.cols, m.is_shared_input};
+  // split: the (d0, d1) of the whole matrix when m is a range of its row blocks, else null (getSplit's own)
+  mmh_fc_plan *fc_plan(const mmh_fc_meta &m, const int64_t *split = nullptr) const {
+    const std::array<int64_t, 5> key{m.rows, m.cols, m.is_shared_input, split ? split[0] : 0, split ? split[1] : 0};
     std::lock_guard<std::mutex> g(plan_mu);
     auto it = fc_plans.find(key);
     if (it != fc_plans.end()) return it->second;
     mmh_fc_plan *plan = nullptr;
-    must(mmh_fc_plan_create(ring.ctx, &m, &plan), "CheetahLinear::fc getSplit");
+    must(split ? mmh_fc_plan_create_split(ring.ctx, &m, split, &plan) : mmh_fc_plan_create(ring.ctx, &m, &plan),
+         "CheetahLinear::fc getSplit");
     return fc_plans[key] = plan;
+  }
+};
+}  // namespace
+
+struct CheetahLinear::Impl : Worker {
+  uint32_t key[8];
+  bool fixed_key = false;  // Options::sampler_key: ciphertext seeds follow the key as well (tests)
+  mutable uint64_t stream_id = 1, seed_count = 0;
+  mm::IOChannel *io = nullptr;
+  std::vector<std::unique_ptr<Worker>> helpers;  // ALICE's devices after the first
+  std::vector<uint64_t> pk_host;                 // BOB's ring public key as received, for the helpers
+
+  ~Impl() {
+    if (stream) (void)mmh_stream_sync(stream);
+    if (staging.p) mmh_host_free(staging.p);
+    if (flag_host) mmh_host_free(flag_host);
   }
   uint64_t sid() const { return stream_id++; }
 
@@ -248,6 +268,7 @@ struct CheetahLinear::Impl {
       if (sz != host.size() * 8) throw std::runtime_error("CheetahLinear: public key size mismatch");
       io->recv_data(host.data(), sz);
       up(k.pk, host.data(), host.size());
+      if (&k == &ring) pk_host = host;
     }
     // pk restricted to the last level {q0}: limb 0 of both polynomials
     std::vector<uint64_t> last(2 * N);
@@ -305,10 +326,15 @@ struct CheetahLinear::Impl {
   };
   Fresh fresh(const mmh_ctx *c, size_t n) const {  // `a` for n ciphertexts at the first level, from a public seed
     Fresh f;
-    FILE *r = std::fopen("/dev/urandom", "rb");
-    const bool ok = r && std::fread(f.seed, 1, sizeof(f.seed), r) == sizeof(f.seed);
-    if (r) std::fclose(r);
-    if (!ok) throw std::runtime_error("CheetahLinear: cannot draw a ciphertext seed");
+    if (fixed_key) {  // tests: the n-th seed is the key with n folded in
+      for (int i = 0; i < 8; ++i) f.seed[i] = key[i] ^ (uint32_t)(0x9E3779B9u * (uint32_t)(seed_count + 1 + i));
+      ++seed_count;
+    } else {
+      FILE *r = std::fopen("/dev/urandom", "rb");
+      const bool ok = r && std::fread(f.seed, 1, sizeof(f.seed), r) == sizeof(f.seed);
+      if (r) std::fclose(r);
+      if (!ok) throw std::runtime_error("CheetahLinear: cannot draw a ciphertext seed");
+    }
     f.a = mk(n * L * N);
     must(mmh_sample_uniform(c, 0, f.seed, 0, f.a.p, n, stream), "sample_uniform");
     return f;
@@ -324,19 +350,33 @@ struct CheetahLinear::Impl {
     io->send_data(staging.p, n * L * N * 8);
     io->flush();
   }
-  Dev recv_fresh(const mmh_ctx *c, size_t expect) const {  // waits for the peer; the rest is enqueued
-    uint32_t n = 0, seed[8];
+  struct Inbound {  // a fresh batch as it came off the wire: c0 at the head of the staging buffer, and a's seed
+    uint32_t seed[8];
+    size_t n = 0;
+  };
+  // waits for the peer; `more_words` of the staging buffer after the batch are the caller's (its outbound bytes)
+  Inbound recv_fresh_host(size_t expect, size_t more_words = 0) const {
+    Inbound in;
+    uint32_t n = 0;
     io->recv_data(&n, sizeof(n));
     if (n != expect) throw std::runtime_error("CheetahLinear: ciphertext count mismatch");
-    io->recv_data(seed, sizeof(seed));
-    const size_t half = (size_t)n * L * N;
-    uint64_t *host = stage(half);
-    io->recv_data(host, half * 8);
-    Dev c0 = mk(half), a = mk(half), cts = mk(2 * half);
-    up(c0, host, half);
-    must(mmh_sample_uniform(c, 0, seed, 0, a.p, n, stream), "sample_uniform");
-    must(mmh_ct_join(c, 0, c0.p, a.p, n, cts.p, stream), "join");
+    io->recv_data(in.seed, sizeof(in.seed));
+    in.n = n;
+    io->recv_data(stage(in.n * L * N + more_words), in.n * L * N * 8);
+    return in;
+  }
+  // the batch on device w (its own device current): copy of c0, expansion of the seed, both enqueued on w's stream.
+  // `c` is w's context of the batch's kind.
+  Dev expand_fresh(const Worker &w, const mmh_ctx *c, const Inbound &in) const {
+    const size_t half = in.n * L * N;
+    Dev c0 = w.mk(half), a = w.mk(half), cts = w.mk(2 * half);
+    w.up(c0, staging.p, half);
+    must(mmh_sample_uniform(c, 0, in.seed, 0, a.p, in.n, w.stream), "sample_uniform");
+    must(mmh_ct_join(c, 0, c0.p, a.p, in.n, cts.p, w.stream), "join");
     return cts;
+  }
+  Dev recv_fresh(const mmh_ctx *c, size_t expect) const {  // waits for the peer; the rest is enqueued
+    return expand_fresh(*this, c, recv_fresh_host(expect));
   }
 
   // conv2DOneFilter's zero-filter verdict (hom_conv2d_ss.cc:573-580), written by the layer call on the device
@@ -392,40 +432,358 @@ struct CheetahLinear::Impl {
       send_staged(n_out, packed_words);
     }
   }
+
+  // ---- ALICE over several devices ---------------------------------------------------------------------------------
+  // A layer's output ciphertexts do not depend on each other, so its server side is cut the way the reference cuts it
+  // over threads (LaunchWorks: contiguous ranges of ceil(n / workers) jobs, hom_conv2d_ss.cc:597-607): ranges of
+  // output filters (conv2d), of row blocks (fc), of ciphertexts (bn).  Every device takes the client's batch from the
+  // one page-locked buffer it was received into (each device has its own link to the host), draws its range of the
+  // layer's randomness (mmh_sample_reshare_range: the wire carries the bytes of the one-device run) and copies its
+  // packed results into its slice of the same buffer, which goes to the channel in one piece.  One host thread
+  // enqueues for all devices (every call is asynchronous), then waits for each stream.
+  size_t team_size() const { return 1 + helpers.size(); }
+  const Worker &member(size_t i) const { return i == 0 ? static_cast<const Worker &>(*this) : *helpers[i - 1]; }
+  struct Range {
+    size_t lo, hi;
+    size_t count() const { return hi - lo; }
+  };
+  static Range cut(size_t total, size_t workers, size_t w) {
+    const size_t per = (total + workers - 1) / workers;
+    return Range{std::min(total, w * per), std::min(total, (w + 1) * per)};
+  }
+  void send_words(size_t n_cts, const uint64_t *host, size_t words) const {
+    uint32_t n = (uint32_t)n_cts;
+    io->send_data(&n, sizeof(n));
+    io->send_data(host, words * 8);
+    io->flush();
+  }
+
+  // input / filters / out: NHWC, HWIO and NHWC raw values (nhwc, as conv2d_nhwc) or [C][H][W] ring elements, the
+  // filter tensors and [M][oh][ow] (as conv2d)
+  void conv_team(const mmh_conv_meta &m, bool nhwc, const uint64_t *input, const uint64_t *filters_hwio,
+                 const std::vector<Tensor<uint64_t>> *filters, uint64_t *out, uint64_t ring_mask) const {
+    mmh_conv_plan *whole = conv_plan(m);
+    size_t n_in, n_cs, n_sp, n_out, packed = 0;
+    int64_t os[3];
+    must(mmh_conv_plan_info(whole, &n_in, &n_cs, &n_sp, &n_out, os, nullptr), "plan_info");
+    must(mmh_conv_result_packed_words(whole, &packed), "CheetahLinear::conv2d");
+    const size_t C = (size_t)m.in_c, H = (size_t)m.in_h, W = (size_t)m.in_w, fh = (size_t)m.f_h, fw = (size_t)m.f_w,
+                 M = (size_t)m.n_filters, f_words = C * fh * fw, img_words = C * H * W, px = (size_t)(os[1] * os[2]);
+    const uint64_t sid0 = stream_id;
+    stream_id += 3;
+    struct Job {
+      const Worker *w = nullptr;
+      Range r{0, 0};
+      mmh_conv_plan *plan = nullptr;
+      const uint64_t *filt_p = nullptr;
+      Dev img, filt, u, e1, mask, out_cts, share, share_t, flag, wire, cts;
+    };
+    std::vector<Job> jobs;
+    for (size_t i = 0; i < team_size(); ++i) {
+      const Range r = cut(M, team_size(), i);
+      if (!r.count()) continue;
+      const Worker &w = member(i);
+      DeviceGuard dg(w.device);
+      Job j;
+      j.w = &w, j.r = r;
+      mmh_conv_meta mw = m;
+      mw.n_filters = (int64_t)r.count();
+      j.plan = w.conv_plan(mw);
+      if (m.is_shared_input) {
+        j.img = w.mk(img_words);
+        if (nhwc) {
+          Dev raw = w.mk(img_words);
+          w.up(raw, input, img_words);
+          must(mmh_repack_nhwc_to_chw(raw.p, H, W, C, ring_mask, j.img.p, w.stream), "repack input");
+        } else {
+          w.up(j.img, input, img_words);
+        }
+      }
+      if (nhwc) {  // the [FH][FW][CI][CO] array is cut along its fastest axis: it crosses whole and is cut on the device
+        Dev fraw = w.mk(M * f_words);
+        j.filt = w.mk(M * f_words);
+        w.up(fraw, filters_hwio, M * f_words);
+        must(mmh_repack_hwio_to_oihw(fraw.p, fh, fw, C, M, ring_mask, j.filt.p, w.stream), "repack filters");
+        j.filt_p = j.filt.p + r.lo * f_words;
+      } else {
+        j.filt = w.mk(r.count() * f_words);
+        for (size_t k = r.lo; k < r.hi; ++k)
+          must(mmh_memcpy_h2d(j.filt.p + (k - r.lo) * f_words, (*filters)[k].data(), f_words * 8, w.stream), "h2d");
+        j.filt_p = j.filt.p;
+      }
+      const size_t cts_w = r.count() * n_sp;
+      j.u = w.mk(cts_w * N), j.e1 = w.mk(cts_w * N), j.mask = w.mk(cts_w * N);
+      must(mmh_sample_reshare_range(w.ring.ctx, key, sid0, r.lo * n_sp, cts_w, (int64_t *)j.u.p, (int64_t *)j.e1.p,
+                                    j.mask.p, w.stream),
+           "sample_reshare");
+      j.out_cts = w.mk(cts_w * 2 * N), j.share = w.mk(r.count() * px), j.flag = w.mk(1);
+      j.wire = w.mk(cts_w * packed);
+      if (nhwc) j.share_t = w.mk(r.count() * px);
+      jobs.push_back(std::move(j));
+    }
+    // page-locked buffer: [client's c0 | packed results | shares | one verdict word per device]
+    const size_t half = n_in * L * N, out_words = M * px;
+    const Inbound in = recv_fresh_host(n_in, n_out * packed + out_words + team_size());
+    uint64_t *wire_h = staging.p + half, *share_h = wire_h + n_out * packed, *flags_h = share_h + out_words;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+      Job &j = jobs[k];
+      const Worker &w = *j.w;
+      DeviceGuard dg(w.device);
+      j.cts = expand_fresh(w, w.ring.ctx, in);
+      must(mmh_conv_server_tensors(j.plan, j.cts.p, m.is_shared_input ? j.img.p : nullptr, j.filt_p, w.ring.pk_last.p,
+                                   (const int64_t *)j.u.p, (const int64_t *)j.e1.p, j.mask.p, j.out_cts.p, j.share.p,
+                                   (uint32_t *)j.flag.p, w.stream),
+           "CheetahLinear::conv2d conv2DSS:");
+      flags_h[k] = 0;
+      must(mmh_memcpy_d2h(flags_h + k, j.flag.p, 4, w.stream), "d2h");
+      must(mmh_conv_result_pack(j.plan, j.out_cts.p, j.wire.p, w.stream), "CheetahLinear::conv2d pack");
+      w.down(wire_h + j.r.lo * n_sp * packed, j.wire, j.r.count() * n_sp * packed);
+      if (nhwc) {
+        must(mmh_repack_chw_to_nhwc(j.share.p, j.r.count(), (size_t)os[1], (size_t)os[2], j.share_t.p, w.stream),
+             "repack output");
+        w.down(share_h + j.r.lo * px, j.share_t, j.r.count() * px);
+      } else {
+        w.down(share_h + j.r.lo * px, j.share, j.r.count() * px);
+      }
+    }
+    for (Job &j : jobs) {
+      DeviceGuard dg(j.w->device);
+      j.w->sync();
+    }
+    for (size_t k = 0; k < jobs.size(); ++k)
+      if ((uint32_t)flags_h[k])
+        throw std::runtime_error("CheetahLinear::conv2d conv2DSS: " + CodeMessage(Code::ERR_INTERNAL));
+    send_words(n_out, wire_h, n_out * packed);
+    if (!nhwc) {
+      std::memcpy(out, share_h, out_words * 8);
+    } else {  // each device left [oh][ow][its filters]; the rows interleave into [oh][ow][M]
+      for (const Job &j : jobs)
+        for (size_t q = 0; q < px; ++q)
+          std::memcpy(out + q * M + j.r.lo, share_h + j.r.lo * px + q * j.r.count(), j.r.count() * 8);
+    }
+  }
+
+  // wd: rows x cols row-major ring elements, or (in_out) cols x rows raw values; the sub-matrix check is the caller's
+  void fc_team(const mmh_fc_meta &m, const uint64_t *vec_h, const uint64_t *wd, bool in_out, uint64_t ring_mask,
+               uint64_t *out) const {
+    mmh_fc_plan *whole = fc_plan(m);
+    int64_t split[2];
+    size_t n_in, n_out;
+    must(mmh_fc_plan_info(whole, split, &n_in, &n_out), "plan_info");
+    const size_t rows = (size_t)m.rows, cols = (size_t)m.cols;
+    const uint64_t sid0 = stream_id;
+    stream_id += 3;
+    struct Job {
+      const Worker *w = nullptr;
+      Range b{0, 0};          // row blocks
+      size_t r0 = 0, r1 = 0;  // their rows
+      mmh_fc_plan *plan = nullptr;
+      Dev wmat, wpts, spts, u, e1, mask, out_cts, share, cts;
+    };
+    std::vector<Job> jobs;
+    for (size_t i = 0; i < team_size(); ++i) {
+      const Range b = cut(n_out, team_size(), i);
+      if (!b.count()) continue;
+      const Worker &w = member(i);
+      DeviceGuard dg(w.device);
+      Job j;
+      j.w = &w, j.b = b, j.r0 = b.lo * (size_t)split[0], j.r1 = std::min(rows, b.hi * (size_t)split[0]);
+      const mmh_fc_meta sub{(int64_t)(j.r1 - j.r0), m.cols, m.is_shared_input};
+      j.plan = w.fc_plan(sub, split);
+      const uint64_t *wp;
+      if (in_out) {  // [cols][rows] -> [rows][cols] on the device, then the block's rows
+        Dev raw = w.mk(rows * cols);
+        j.wmat = w.mk(rows * cols);
+        w.up(raw, wd, rows * cols);
+        must(mmh_repack_hwio_to_oihw(raw.p, 1, 1, cols, rows, ring_mask, j.wmat.p, w.stream), "CheetahLinear::fc transpose");
+        wp = j.wmat.p + j.r0 * cols;
+      } else {
+        j.wmat = w.mk((j.r1 - j.r0) * cols);
+        w.up(j.wmat, wd + j.r0 * cols, (j.r1 - j.r0) * cols);
+        wp = j.wmat.p;
+      }
+      j.wpts = w.mk(b.count() * n_in * N);
+      must(mmh_fc_encode_weights(j.plan, wp, j.wpts.p, w.stream), "CheetahLinear::fc encodeWeightMatrix error");
+      if (m.is_shared_input) {
+        Dev vec = w.mk(cols);
+        w.up(vec, vec_h, cols);
+        j.spts = w.mk(n_in * N);
+        must(mmh_fc_encode_input(j.plan, vec.p, j.spts.p, w.stream), "CheetahLinear::fc encodeInputVector error");
+      }
+      j.u = w.mk(b.count() * N), j.e1 = w.mk(b.count() * N), j.mask = w.mk(b.count() * N);
+      must(mmh_sample_reshare_range(w.ring.ctx, key, sid0, b.lo, b.count(), (int64_t *)j.u.p, (int64_t *)j.e1.p, j.mask.p,
+                                    w.stream),
+           "sample_reshare");
+      j.out_cts = w.mk(b.count() * 2 * N), j.share = w.mk(j.r1 - j.r0);
+      jobs.push_back(std::move(j));
+    }
+    const size_t half = n_in * L * N;
+    const Inbound in = recv_fresh_host(n_in, n_out * 2 * N + rows);
+    uint64_t *wire_h = staging.p + half, *share_h = wire_h + n_out * 2 * N;
+    for (Job &j : jobs) {
+      const Worker &w = *j.w;
+      DeviceGuard dg(w.device);
+      j.cts = expand_fresh(w, w.ring.ctx, in);
+      must(mmh_fc_server(j.plan, j.cts.p, j.spts.p, j.wpts.p, w.ring.pk_last.p, (const int64_t *)j.u.p,
+                         (const int64_t *)j.e1.p, j.mask.p, j.out_cts.p, j.share.p, w.stream),
+           "CheetahLinear::fc matmul2D error");
+      w.down(share_h + j.r0, j.share, j.r1 - j.r0);
+      w.down(wire_h + j.b.lo * 2 * N, j.out_cts, j.b.count() * 2 * N);
+    }
+    for (Job &j : jobs) {
+      DeviceGuard dg(j.w->device);
+      j.w->sync();
+    }
+    send_words(n_out, wire_h, n_out * 2 * N);
+    std::memcpy(out, share_h, rows * 8);
+  }
+
+  // HomBNSS::bn (SIMD path): ranges of the vector's ciphertexts
+  void bn_team(size_t n, bool shared, const uint64_t *in_h, const uint64_t *scale_h, uint64_t *out) const {
+    const size_t sub = std::min(n, N), n_ct = (n + sub - 1) / sub;
+    const uint64_t rsid = sid();
+    struct Job {
+      const Worker *w = nullptr;
+      Range c{0, 0};          // ciphertexts
+      size_t e0 = 0, e1 = 0;  // their elements
+      Dev sc_pts, in_pts, rnd, out_cts, share, cts;
+    };
+    std::vector<Job> jobs;
+    for (size_t i = 0; i < team_size(); ++i) {
+      const Range c = cut(n_ct, team_size(), i);
+      if (!c.count()) continue;
+      const Worker &w = member(i);
+      DeviceGuard dg(w.device);
+      Job j;
+      j.w = &w, j.c = c, j.e0 = c.lo * sub, j.e1 = std::min(n, c.hi * sub);
+      const size_t cnt = j.e1 - j.e0;
+      Dev scale = w.mk(cnt);
+      w.up(scale, scale_h + j.e0, cnt);
+      j.sc_pts = w.mk(c.count() * N);
+      must(mmh_bn_encode_vector(w.field.ctx, scale.p, cnt, j.sc_pts.p, w.stream), "bn encodeScales");
+      if (shared) {
+        Dev vec = w.mk(cnt);
+        w.up(vec, in_h + j.e0, cnt);
+        j.in_pts = w.mk(c.count() * N);
+        must(mmh_bn_encode_vector(w.field.ctx, vec.p, cnt, j.in_pts.p, w.stream), "bn encodeVector");
+      }
+      j.rnd = w.mk(cnt);  // words [e0, e1) of the vector's mask stream (e0 is a multiple of N, a block holds 8 words)
+      must(mmh_chacha20_words(key, rsid, j.e0 / 8, j.rnd.p, cnt, w.stream), "chacha20");
+      j.out_cts = w.mk(c.count() * 2 * N), j.share = w.mk(cnt);
+      jobs.push_back(std::move(j));
+    }
+    const size_t half = n_ct * L * N;
+    const Inbound in = recv_fresh_host(n_ct, n_ct * 2 * N + n);
+    uint64_t *wire_h = staging.p + half, *share_h = wire_h + n_ct * 2 * N;
+    for (Job &j : jobs) {
+      const Worker &w = *j.w;
+      DeviceGuard dg(w.device);
+      j.cts = expand_fresh(w, w.field.ctx, in);
+      must(mmh_bn_server(w.field.ctx, j.cts.p + j.c.lo * 2 * L * N, j.in_pts.p, j.sc_pts.p, j.e1 - j.e0, j.rnd.p,
+                         j.out_cts.p, j.share.p, w.stream),
+           "bn failed");
+      w.down(share_h + j.e0, j.share, j.e1 - j.e0);
+      w.down(wire_h + j.c.lo * 2 * N, j.out_cts, j.c.count() * 2 * N);
+    }
+    for (Job &j : jobs) {
+      DeviceGuard dg(j.w->device);
+      j.w->sync();
+    }
+    send_words(n_ct, wire_h, n_ct * 2 * N);
+    std::memcpy(out, share_h, n * 8);
+  }
 };
 
-CheetahLinear::CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, size_t /*nthreads*/, int device)
+namespace {
+// MM_GEMINI_DEVICES="0,1,..." gives the device list to callers that only know the reference's constructor
+// (InitLinear in library.cc, the tests' drivers)
+CheetahLinear::Options legacy_options(size_t nthreads, int device) {
+  CheetahLinear::Options opt;
+  opt.nthreads = nthreads;
+  opt.devices.assign(1, device);
+  if (const char *env = std::getenv("MM_GEMINI_DEVICES")) {
+    std::vector<int> list;
+    for (const char *p = env; *p;) {
+      char *end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p || v < 0) throw std::invalid_argument("CheetahLinear: MM_GEMINI_DEVICES is not a list of devices");
+      list.push_back((int)v);
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') throw std::invalid_argument("CheetahLinear: MM_GEMINI_DEVICES is not a list of devices");
+    }
+    if (!list.empty()) opt.devices = list;
+  }
+  return opt;
+}
+}  // namespace
+
+CheetahLinear::CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, size_t nthreads, int device)
+    : CheetahLinear(party, io, base_mod, legacy_options(nthreads, device)) {}
+
+CheetahLinear::CheetahLinear(int party, mm::IOChannel *io, uint64_t base_mod, const Options &opt)
     : party_(party), io_(io), base_mod_(base_mod), impl_(new Impl()) {
   if (base_mod < 2ULL || (int)std::log2(base_mod) >= 45)  // cheetah-api.cpp:76-78
     throw std::logic_error("CheetahLinear: base_mod out-of-bound [2, 2^45)");
   if (party != kAlice && party != kBob) throw std::invalid_argument("CheetahLinear: party");
+  if (opt.devices.empty()) throw std::invalid_argument("CheetahLinear: no device");
+  const int device = opt.devices[0];
   impl_->io = io;
   impl_->device = device;
-  FILE *f = std::fopen("/dev/urandom", "rb");
-  if (!f || std::fread(impl_->key, 1, sizeof(impl_->key), f) != sizeof(impl_->key)) {
-    if (f) std::fclose(f);
-    throw std::runtime_error("CheetahLinear: cannot seed the sampler");
+  if (opt.sampler_key) {
+    std::copy(opt.sampler_key, opt.sampler_key + 8, impl_->key);
+    impl_->fixed_key = true;
+  } else {
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    if (!f || std::fread(impl_->key, 1, sizeof(impl_->key), f) != sizeof(impl_->key)) {
+      if (f) std::fclose(f);
+      throw std::runtime_error("CheetahLinear: cannot seed the sampler");
+    }
+    std::fclose(f);
   }
-  std::fclose(f);
-  DeviceGuard dg(device);
-  must(mmh_stream_create(&impl_->stream), "stream");
-  const int bits[2] = {60, 49};  // :99-103
-  must(mmh_ctx_create_bits(&impl_->ring.ctx, Impl::N, bits, 2, base_mod, device), "SEALContext");
-  impl_->setup_keys(impl_->ring, party);
   const bool is_mod_2k = (base_mod & (base_mod - 1)) == 0;
   if (!is_mod_2k) throw std::runtime_error("Not implemented yet.");  // :143-147
   field_mod_ = kFieldPrimes.at((int)std::log2(base_mod));            // setUpForBN :153
-  must(mmh_ctx_create_bits(&impl_->field.ctx, Impl::N, bits, 2, field_mod_, device), "SEALContext (SIMD)");
-  impl_->setup_keys(impl_->field, party);
+  const int bits[2] = {60, 49};                                      // :99-103
+  {
+    DeviceGuard dg(device);
+    must(mmh_stream_create(&impl_->stream), "stream");
+    must(mmh_ctx_create_bits(&impl_->ring.ctx, Impl::N, bits, 2, base_mod, device), "SEALContext");
+    impl_->setup_keys(impl_->ring, party);
+    must(mmh_ctx_create_bits(&impl_->field.ctx, Impl::N, bits, 2, field_mod_, device), "SEALContext (SIMD)");
+    impl_->setup_keys(impl_->field, party);
+  }
+  // ALICE's further devices: contexts and BOB's ring public key (the SIMD path's server side uses no key)
+  for (size_t i = 1; party == kAlice && i < opt.devices.size(); ++i) {
+    std::unique_ptr<Worker> w(new Worker());
+    w->device = opt.devices[i];
+    DeviceGuard dg(w->device);
+    must(mmh_stream_create(&w->stream), "stream");
+    must(mmh_ctx_create_bits(&w->ring.ctx, Impl::N, bits, 2, base_mod, w->device), "SEALContext");
+    must(mmh_ctx_create_bits(&w->field.ctx, Impl::N, bits, 2, field_mod_, w->device), "SEALContext (SIMD)");
+    const std::vector<uint64_t> &pk = impl_->pk_host;
+    std::vector<uint64_t> last(2 * Impl::N);
+    std::copy(pk.begin(), pk.begin() + Impl::N, last.begin());
+    std::copy(pk.begin() + Impl::L * Impl::N, pk.begin() + Impl::L * Impl::N + Impl::N, last.begin() + Impl::N);
+    w->ring.pk = w->mk(pk.size());
+    w->ring.pk_last = w->mk(last.size());
+    w->up(w->ring.pk, pk.data(), pk.size());
+    w->up(w->ring.pk_last, last.data(), last.size());
+    w->sync();
+    impl_->helpers.push_back(std::move(w));
+  }
 }
 
 CheetahLinear::~CheetahLinear() = default;
 
 void CheetahLinear::release_device_buffers() const {
-  DeviceGuard dg(impl_->device);
-  impl_->sync();
-  impl_->pool.release();
+  for (size_t i = 0; i < impl_->team_size(); ++i) {
+    const Worker &w = impl_->member(i);
+    DeviceGuard dg(w.device);
+    w.sync();
+    w.pool.release();
+  }
 }
+size_t CheetahLinear::n_devices() const { return impl_->team_size(); }
 
 void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<Tensor<uint64_t>> &filters,
                            const ConvMeta &meta, Tensor<uint64_t> &out_tensor) const {
@@ -443,6 +801,11 @@ void CheetahLinear::conv2d(const Tensor<uint64_t> &in_tensor, const std::vector<
   int64_t oshape[3];
   must(mmh_conv_plan_info(plan, &n_in, &n_cs, &n_sp, &n_out, oshape, nullptr), "plan_info");
   TensorShape out_shape({oshape[0], oshape[1], oshape[2]});
+  if (party_ == kAlice && I.team_size() > 1 && meta.n_filters > 1) {
+    if (!out_tensor.shape().IsSameSize(out_shape)) out_tensor.Reshape(out_shape);
+    I.conv_team(m, false, in_tensor.data(), nullptr, &filters, out_tensor.data(), base_mod_ - 1);
+    return;
+  }
   if (!out_tensor.shape().IsSameSize(out_shape)) out_tensor.Reshape(out_shape);
   const size_t img_words = (size_t)meta.ishape.num_elements(), out_words = (size_t)out_shape.num_elements();
   Dev img = I.mk(img_words), out = I.mk(out_words), dfilt;
@@ -476,6 +839,10 @@ void CheetahLinear::conv2d_nhwc(const uint64_t *input_nhwc, const uint64_t *filt
     throw std::runtime_error("Conv2DWrapper: output shape differs from the caller's (pads / stride)");
   const size_t img_words = C * H * W, out_words = (size_t)(oshape[0] * oshape[1] * oshape[2]);
   const uint64_t ring_mask = base_mod_ - 1;  // getRingElt
+  if (party_ == kAlice && I.team_size() > 1 && M > 1) {
+    I.conv_team(m, true, input_nhwc, filters_hwio, nullptr, out_nhwc, ring_mask);
+    return;
+  }
   Dev raw = I.mk(img_words), img = I.mk(img_words), out = I.mk(out_words), out_t = I.mk(out_words), dfilt;
   I.up(raw, input_nhwc, img_words);
   must(mmh_repack_nhwc_to_chw(raw.p, H, W, C, ring_mask, img.p, I.stream), "repack input");
@@ -531,15 +898,6 @@ void CheetahLinear::fc_any(const Tensor<uint64_t> &input_vector, const uint64_t 
     I.down(out_vec_share.data(), out, rows);
     I.sync();
   } else {
-    Dev w = I.mk(rows * cols), wpts = I.mk(n_out * n_in * N), spts;
-    if (in_out) {  // [cols][rows] -> [rows][cols], reduced into the ring on the way
-      Dev raw = I.mk(rows * cols);
-      I.up(raw, wd, rows * cols);
-      must(mmh_repack_hwio_to_oihw(raw.p, 1, 1, cols, rows, base_mod_ - 1, w.p, I.stream), "CheetahLinear::fc transpose");
-    } else {
-      I.up(w, wd, rows * cols);
-    }
-    must(mmh_fc_encode_weights(plan, w.p, wpts.p, I.stream), "CheetahLinear::fc encodeWeightMatrix error");
     {  // matVecMul rejects a sub-matrix that encodes to zero (hom_fc_ss.cc:414-422); base_mod is a power of two (ctor)
       int64_t split[2];
       must(mmh_fc_plan_info(plan, split, nullptr, nullptr), "plan_info");
@@ -560,6 +918,19 @@ void CheetahLinear::fc_any(const Tensor<uint64_t> &input_vector, const uint64_t 
       for (uint8_t v : nz)
         if (!v) throw std::runtime_error("CheetahLinear::fc matmul2D error [" + CodeMessage(Code::ERR_INVALID_ARG) + "]");
     }
+    if (I.team_size() > 1 && n_out > 1) {
+      I.fc_team(m, input_vector.data(), wd, in_out, base_mod_ - 1, out_vec_share.data());
+      return;
+    }
+    Dev w = I.mk(rows * cols), wpts = I.mk(n_out * n_in * N), spts;
+    if (in_out) {  // [cols][rows] -> [rows][cols], reduced into the ring on the way
+      Dev raw = I.mk(rows * cols);
+      I.up(raw, wd, rows * cols);
+      must(mmh_repack_hwio_to_oihw(raw.p, 1, 1, cols, rows, base_mod_ - 1, w.p, I.stream), "CheetahLinear::fc transpose");
+    } else {
+      I.up(w, wd, rows * cols);
+    }
+    must(mmh_fc_encode_weights(plan, w.p, wpts.p, I.stream), "CheetahLinear::fc encodeWeightMatrix error");
     if (meta.is_shared_input) {
       spts = I.mk(n_in * N);
       must(mmh_fc_encode_input(plan, vec.p, spts.p, I.stream), "CheetahLinear::fc encodeInputVector error");
@@ -602,6 +973,10 @@ void CheetahLinear::bn(const Tensor<uint64_t> &input_vector, const Tensor<uint64
     I.sync();
   } else {
     if (!scale_vector.shape().IsSameSize(meta.vec_shape)) throw std::runtime_error("bn scale_vector shape mismatch");
+    if (I.team_size() > 1 && n_ct > 1) {
+      I.bn_team(n, meta.is_shared_input, input_vector.data(), scale_vector.data(), out_vector.data());
+      return;
+    }
     Dev scale = I.mk(n), sc_pts = I.mk(n_ct * N), in_pts;
     I.up(scale, scale_vector.data(), n);
     must(mmh_bn_encode_vector(I.field.ctx, scale.p, n, sc_pts.p, I.stream), "bn encodeScales");

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mmh_device_count": [C.POINTER(_int)],
     "mmh_conv_plan_work": [_vp, _vp],
     "mmh_sample_reshare": [_vp, C.POINTER(C.c_uint32), _u64, _sz, _vp, _vp, _vp, _vp],
+    "mmh_sample_reshare_range": [_vp, C.POINTER(C.c_uint32), _u64, _sz, _sz, _vp, _vp, _vp, _vp],
     "mmh_ctx_create": [C.POINTER(_vp), _sz, C.POINTER(_u64), _sz, _u64, _int],
     "mmh_ctx_create_bits": [C.POINTER(_vp), _sz, C.POINTER(_int), _sz, _u64, _int],
     "mmh_ctx_destroy": [_vp],
@@ -123,6 +124,7 @@ SIGNATURES = {
     "mmh_conv_result_pack": [_vp, _vp, _vp, _vp],
     "mmh_conv_result_unpack": [_vp, _vp, _vp, _vp],
     "mmh_fc_plan_create": [_vp, _vp, C.POINTER(_vp)],
+    "mmh_fc_plan_create_split": [_vp, _vp, C.POINTER(C.c_int64), C.POINTER(_vp)],
     "mmh_fc_plan_destroy": [_vp],
     "mmh_fc_split": [C.c_int64, C.c_int64, _sz, C.POINTER(C.c_int64)],
     "mmh_fc_plan_info": [_vp, C.POINTER(C.c_int64), C.POINTER(_sz), C.POINTER(_sz)],
@@ -462,6 +464,13 @@ class Sampler:
         self.next_stream += 3
         check(self.ctx.lib.mmh_sample_reshare(self.ctx.handle, self.key, sid, n_polys, dptr(u), dptr(e1), dptr(mask),
                                               _stream_ptr()))
+        return u, e1, mask
+
+    def reshare_range(self, sid, first_poly, n_polys):
+        """polynomials [first_poly, first_poly + n_polys) of the draw reshare() makes on streams sid .. sid + 2"""
+        u, e1, mask = (self.ctx._empty(n_polys, self.ctx.N) for _ in range(3))
+        check(self.ctx.lib.mmh_sample_reshare_range(self.ctx.handle, self.key, sid, first_poly, n_polys, dptr(u),
+                                                    dptr(e1), dptr(mask), _stream_ptr()))
         return u, e1, mask
 
     def keygen(self):

@@ -157,6 +157,8 @@ int main(int argc, char **argv) {
     lib[s].field_mod = linear[s]->field_mod(), lib[s].cheetah_linear = linear[s].get(), lib[s].truncation = trunc[s].get();
   });
 
+  std::printf("server side on %zu device worker(s)%s\n", linear[0]->n_devices(),
+              std::getenv("MM_GEMINI_DEVICES") ? " (MM_GEMINI_DEVICES)" : "");
   int layers = 0, bns = 0, failures = 0;
   long plus2_total = 0;
   double total_ms = 0, cold_ms = 0, bn_ms = 0;

@@ -91,6 +91,20 @@ def test_reshare_launch_equals_the_three_samplers(mm):
         assert a.next_stream == b.next_stream
 
 
+def test_reshare_range_is_a_slice_of_the_whole_draw(mm):
+    """mmh_sample_reshare_range(first, n) = rows [first, first + n) of mmh_sample_reshare: ranges that start and end
+    inside tiles of every kind (a noise tile is 3072 samples, a polynomial 4096)"""
+    import torch
+    g = mm.Context(N, (60, 49), 1 << 37)
+    smp = mm.Sampler(g, key=bytes(range(32)))
+    sid = smp.next_stream
+    whole = smp.reshare(23)
+    for first, n in ((0, 23), (1, 1), (5, 7), (22, 1), (11, 12)):
+        part = smp.reshare_range(sid, first, n)
+        for w, p in zip(whole, part):
+            assert torch.equal(w[first:first + n], p)
+
+
 def test_sample_mapping_against_the_block_function(mm):
     """the three distributions spend the keystream as include/mm_hip.h / sampler.hip say: thread t of tile T owns
     block 256 T + t and its j-th sample is element 256 W T + 256 j + t (W = 16 ternary from 32-bit words, 12 noise
