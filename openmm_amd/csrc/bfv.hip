@@ -15,14 +15,15 @@ int ntt_signed_dispatch(const mmh_ctx *ctx, const int64_t *d_src, u64 *d_out, si
 int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, size_t n, const u64 *d_acc,
                             const int64_t *d_e1, const u64 *d_mask, u64 *d_out, const uint8_t *d_keep,
                             size_t keep_period, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
-                            hipStream_t s);
+                            hipStream_t s, bool acc_switched);
 int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, u64 *d_out, size_t n,
                              int limbs, hipStream_t s);
 int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n_polys, int limbs,
                       hipStream_t s);
 int reshare_online_dispatch(const mmh_ctx *ctx, const u64 *d_zero, size_t n, const u64 *d_acc, const int64_t *d_e1,
                             const u64 *d_mask, u64 *d_out, const uint8_t *d_keep, size_t keep_period,
-                            const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s);
+                            const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s,
+                            bool acc_switched);
 
 // call-scoped scratch buffer (stream-ordered reuse, see scratch_alloc)
 struct StreamBuf {
@@ -677,7 +678,7 @@ namespace mmh {
 int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
                           const int64_t *d_u, const u64 *d_u_ntt, const int64_t *d_e1, const u64 *d_mask,
                           const uint8_t *d_keep, size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst,
-                          size_t share_plane, u64 *d_share_out);
+                          size_t share_plane, u64 *d_share_out, bool acc_switched = false);
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
                         const int64_t *d_u,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period,
@@ -686,12 +687,15 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
                                keep_period, d_out, s, d_share_dst, share_plane, d_share_out);
 }
 // d_u_ntt: u already transformed (the front launch of a direct-route layer does it beside its own work), else null
+// acc_switched: d_acc holds the accumulator AFTER divide_and_round_q_last, [n][2][N] canonical mod q0 in coefficient
+// form (the matrix-core product's paired items write it so), instead of [n][2][2][N] at the first level
 int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
                           const int64_t *d_u, const u64 *d_u_ntt, const int64_t *d_e1, const u64 *d_mask,
                           const uint8_t *d_keep, size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst,
-                          size_t share_plane, u64 *d_share_out) {
+                          size_t share_plane, u64 *d_share_out, bool acc_switched) {
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  MMH_REQUIRE(!(acc_switched && acc_ntt_form), MMH_ERR_INTERNAL);
   const size_t N = ctx->N;
   StreamBuf u(s);
   if (!d_u_ntt) MMH_HIP(u.alloc(n * N * 8));
@@ -712,12 +716,12 @@ int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, siz
     MMH_HIP(z.alloc(n * 2 * N * 8));
     CHECK_RC(ntt_inv_product_dispatch(ctx, d_u_ntt, d_pk_ntt_last, z.as<u64>(), n, 1, s));
     return reshare_online_dispatch(ctx, z.as<u64>(), n, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst,
-                                   share_plane, d_share_out, s);
+                                   share_plane, d_share_out, s, acc_switched);
   }
   // u * pk_j back to coefficient form and, coefficient by coefficient, into the tail (ReshareSink, ntt.hip): the
   // encryption of zero is never written
   CHECK_RC(ntt_inv_product_reshare(ctx, d_u_ntt, d_pk_ntt_last, n, d_acc, d_e1, d_mask, d_out, d_keep,
-                                   keep_period, d_share_dst, share_plane, d_share_out, s));
+                                   keep_period, d_share_dst, share_plane, d_share_out, s, acc_switched));
   return MMH_OK;
 }
 }  // namespace mmh
@@ -730,12 +734,14 @@ int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, siz
 namespace mmh {
 int reshare_tail_online(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_zero,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period, u64 *d_out,
-                        hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out) {
+                        hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
+                        bool acc_switched = false) {
   if (n == 0) return MMH_OK;
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
+  MMH_REQUIRE(!(acc_switched && acc_ntt_form), MMH_ERR_INTERNAL);
   if (acc_ntt_form) CHECK_RC(ntt_dispatch(ctx, true, d_acc, n * 2, 2, 0, s));
   return reshare_online_dispatch(ctx, d_zero, n, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst,
-                                 share_plane, d_share_out, s);
+                                 share_plane, d_share_out, s, acc_switched);
 }
 }  // namespace mmh
 extern "C" int mmh_reshare_zero_prepare(const mmh_ctx *ctx, const uint64_t *d_pk_ntt_last, const int64_t *d_u, size_t n,

@@ -5,6 +5,7 @@
 #include "bfv_device.hpp"
 #include "common.hpp"
 #include "geometry.hpp"
+#include "host_math.hpp"
 #include "ntt_device.hpp"
 
 #include <cstdlib>
@@ -21,10 +22,11 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
 int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
                           const int64_t *d_u, const u64 *d_u_ntt, const int64_t *d_e1, const u64 *d_mask,
                           const uint8_t *d_keep, size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst,
-                          size_t share_plane, u64 *d_share_out);
+                          size_t share_plane, u64 *d_share_out, bool acc_switched = false);
 int reshare_tail_online(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_zero,
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period, u64 *d_out,
-                        hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out);
+                        hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
+                        bool acc_switched = false);
 int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
                         int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
                         hipStream_t s);
@@ -611,17 +613,6 @@ __global__ __launch_bounds__(256) void pw_expand_kernel(const u64 *__restrict__ 
   planes(hi, 4);
 }
 
-// One step of x mod (2^b - c) on a value held in 32-bit words w3:w2:w1:w0: (x mod 2^b) + (x >> b) * c with
-// b = 32 + s, 8 <= s <= 30, w3 < 2^s.  Funnel shifts and two v_mad_u64_u32: a 64-bit shift by a register amount
-// costs several times as much.  The result is below 2^96 (w3 becomes 0).
-__device__ __forceinline__ void fold_words(u32 &w0, u32 &w1, u32 &w2, u32 w3, u32 c, u32 s, u32 smask) {
-  const u32 h0 = __builtin_amdgcn_alignbit(w2, w1, s), h1 = __builtin_amdgcn_alignbit(w3, w2, s);
-  const u64 t0 = mad32(h0, c, make64(w0, w1 & smask));   // below 2^64: the low part < 2^62, the product < 2^63
-  const u64 t1 = mul32(h1, c);
-  const u64 m1 = (u64)hi32(t0) + lo32(t1);
-  w0 = lo32(t0), w1 = lo32(m1), w2 = hi32(t1) + hi32(m1);
-}
-
 // A workgroup of 8 waves works on an item of (at most) 128 filters x 64 columns at a time (PwItems below); wave
 // (wm, wn) owns half of the item's filters (4, 2 or 1 tiles of 16) and columns 16 wn .. +15.  Per 64-channel step the 32 KiB of column digits and 16/24 KiB of weight digits are
 // copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging registers; both images are
@@ -646,22 +637,35 @@ struct PwLift {   // where the lifted weights come from when no wl array was wri
   ModC t;
   u64 thr;
 };
-__device__ __noinline__ void pw_general_tile(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
-                                             const u64 *__restrict__ wl, u64 *__restrict__ acc, int M, int Mpad,
-                                             int Cpad, size_t S, int logN, const DevMod *__restrict__ mods, size_t c0,
-                                             int mt, const PwLift &lift) {
+// What a paired item (below) needs of the modulus switch: q1^-1 mod q0 with its Shoup quotient, floor(q1 / 2) and
+// that value modulo q0 (divide_and_round_q_last, the first step of the re-sharing tail).
+struct PwSwitch {
+  u64 inv_qlast, inv_qlast_sh, half1, half0;
+};
+// divide_and_round_q_last of one coefficient from its two residues: last = [a1 + q1/2]_q1 read as an integer
+// (q1 < q0), result ((a0 - last + half0) q1^-1) mod q0, canonical -- the value the tail's switched_plus adds to the
+// encryption of zero (ntt.hip), so the tail reads one word where it read two.
+__device__ __forceinline__ u64 pw_switch_last(u64 a1, u64 q1, const PwSwitch &sw) { return csub(a1 + sw.half1, q1); }
+__device__ __forceinline__ u64 pw_switch_finish(u64 a0_minus_last, u64 q0, const PwSwitch &sw) {
+  const u64 y = shoup_mad_uniform(0, a0_minus_last + sw.half0, sw.inv_qlast, sw.inv_qlast_sh, 0 - q0);   // [0, 3 q0)
+  return csub(csub(y, 2 * q0), q0);
+}
+__device__ __noinline__ bool pw_general_core(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+                                             const u64 *__restrict__ wl, int M, int Mpad, int Cpad, size_t S, int logN,
+                                             const DevMod *__restrict__ mods, size_t c0, int mt, const PwLift &lift,
+                                             u64 (&x0)[16]) {
   const int N = 1 << logN, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t cols = S * 4 * N, col = c0 + lane;
+  const size_t col = c0 + lane;
   const int i = (int)(col & (N - 1)), pl = (int)((c0 >> logN) & 3), l = pl & 1;
   const size_t sp = c0 >> (logN + 2);
   const int mbase = mt * 128 + wave * 16;
-  if (mbase >= M) return;
+  if (mbase >= M) return false;
   const DevMod q = mods[l];
   const u64 *__restrict__ base = image + ((sp * 4 + pl) << logN);
   const size_t row_step = S * 4 * N;
   const u64 *__restrict__ wg = wl + (size_t)l * Cpad * Mpad + mbase;
   const int nf = min(16, Mpad - mbase);
-  u64 x0[16], x1[16];
+  u64 x1[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) x0[j] = x1[j] = 0;
   for (int k = 0; k < Cpad; ++k) {
@@ -686,9 +690,40 @@ __device__ __noinline__ void pw_general_tile(const u64 *__restrict__ image, cons
       for (int j = 0; j < 16; ++j) x0[j] = reduce128_wide(x1[j], x0[j], q), x1[j] = 0;
     }
   }
+  return true;
+}
+__device__ __forceinline__ void pw_general_tile(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+                                                const u64 *__restrict__ wl, u64 *__restrict__ acc, int M, int Mpad,
+                                                int Cpad, size_t S, int logN, const DevMod *__restrict__ mods, size_t c0,
+                                                int mt, const PwLift &lift) {
+  const size_t cols = S * 4 * (size_t(1) << logN), col = c0 + (threadIdx.x & 63);
+  const int mbase = mt * 128 + (int)(threadIdx.x >> 6) * 16;
+  u64 x0[16];
+  if (!pw_general_core(image, chan, wl, M, Mpad, Cpad, S, logN, mods, c0, mt, lift, x0)) return;
 #pragma unroll
   for (int j = 0; j < 16; ++j)
     if (mbase + j < M) acc[(size_t)(mbase + j) * cols + col] = x0[j];
+}
+// The same for a paired item: both limbs of the tile at c0 (the limb-0 tile; its partner sits N columns on), the
+// mod-switched value written in the one-limb layout [M][S][2][N].
+__device__ __forceinline__ void pw_general_pair(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+                                                const u64 *__restrict__ wl, u64 *__restrict__ acc, int M, int Mpad,
+                                                int Cpad, size_t S, int logN, const DevMod *__restrict__ mods, size_t c0,
+                                                int mt, const PwLift &lift, const PwSwitch &sw) {
+  const size_t N = size_t(1) << logN, cols = S * 2 * N;
+  const size_t sp = c0 >> (logN + 2), k = (c0 >> (logN + 1)) & 1, i = (c0 & (N - 1)) + (threadIdx.x & 63);
+  const size_t col = ((sp * 2 + k) << logN) + i;
+  const int mbase = mt * 128 + (int)(threadIdx.x >> 6) * 16;
+  u64 a1[16], a0[16];
+  if (!pw_general_core(image, chan, wl, M, Mpad, Cpad, S, logN, mods, c0 + N, mt, lift, a1)) return;
+  (void)pw_general_core(image, chan, wl, M, Mpad, Cpad, S, logN, mods, c0, mt, lift, a0);
+  const u64 q0 = mods[0].q, q1 = mods[1].q;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (mbase + j < M) {
+      const u64 last = pw_switch_last(a1[j], q1, sw);
+      acc[(size_t)(mbase + j) * cols + col] = pw_switch_finish(a0[j] >= last ? a0[j] - last : a0[j] + q0 - last, q0, sw);
+    }
 }
 
 // The work of one launch as a list of items, item = one live 64-column tile x a block of filters.  The launch has one
@@ -706,6 +741,10 @@ struct PwItems {
   int F_log;     // 7, 6 or 5
   int s_log;     // 0, 1 or 2
   int skip7;     // bit l: modulus l is below 2^54, so the eighth column digit is 0 throughout and its products are left out
+  // An item owns BOTH limbs of its 64 columns (live tiles are listed in pairs: limb 1, then limb 0): the steps of limb
+  // 1 first, its residues mod-switched against limb 0's on chip, one word written per coefficient (PwSwitch).  The
+  // column-tile index of an item then counts pairs.
+  int paired;
 };
 static PwItems pw_items(int n_live, int M, int n_cu) {
   PwItems it;
@@ -718,8 +757,54 @@ static PwItems pw_items(int n_live, int M, int n_cu) {
   while (it.s_log < 2 && it.F_log - (it.s_log + 1) >= 5 && (rem << (it.s_log + 1)) <= n_cu) ++it.s_log;
   it.n_items = it.n_main + (rem << it.s_log);
   it.skip7 = 0;
+  it.paired = 0;
   return it;
 }
+
+// One output of the product from its ten biased digit sums: value = sum_d (p[d] - 2^28) 256^d, signed, below 2^100 in
+// magnitude.  The biased digits are assembled into 128 bits, k*q - bias is added (k*q in [2^101, 2^102)) to land on a
+// non-negative representative below 2^103, then reduced: two folds of q = 2^b - c where the modulus has that shape,
+// else Barrett.  Canonical result.
+// (written on 32-bit words with v_mad_u64_u32 and funnel shifts; hipcc's 64-bit shifts by a register amount and its
+// 128-bit adds made the epilogue a tenth of the kernel)
+struct PwRed {
+  const DevMod &q;
+  u32 o0, o1, o2, o3, fc, fs, fmask;
+  bool folds;
+  __device__ __forceinline__ explicit PwRed(const DevMod &q_) : q(q_) {
+    const u32 qbits = 64 - (u32)__builtin_clzll(q.q), sh = 102 - qbits;   // q << sh in [2^101, 2^102)
+    const u64 kq_lo = q.q << sh, kq_hi = q.q >> (64 - sh);
+    const u64 off_lo = kq_lo - 0x1010101010000000ull, off_hi = kq_hi - 0x1010101010ull - (kq_lo < 0x1010101010000000ull);
+    const u32 fbits = q.fold_shift + 32;
+    fc = q.fold_c, fs = q.fold_shift, fmask = q.fold_mask;
+    // fold bounds: x < 2^103 -> x1 < 2^b + 2^(103-b) c (bits1 bits) -> x2 < 2^b + (x1 >> b) c (bits2 bits, must fit a word)
+    folds = fc != 0 && fbits >= 40 && fbits <= 62;
+    if (folds) {
+      const u32 cb = 32 - (u32)__builtin_clz(fc);
+      const u32 bits1 = max(fbits, 103 - fbits + cb) + 1;
+      const u32 bits2 = max(fbits, bits1 - fbits + cb) + 1;
+      folds = bits1 <= 64 + fbits && bits2 <= 64;
+    }
+    o0 = lo32(off_lo), o1 = hi32(off_lo), o2 = lo32(off_hi), o3 = hi32(off_hi);
+  }
+  __device__ __forceinline__ u64 operator()(const u32 (&p)[10]) const {
+    const u64 lo = mad32(p[3], 1u << 24, mad32(p[2], 1u << 16, mad32(p[1], 1u << 8, p[0])));
+    const u64 mid = mad32(p[7], 1u << 24, mad32(p[6], 1u << 16, mad32(p[5], 1u << 8, p[4])));
+    const u64 top = mad32(p[9], 1u << 8, p[8]);
+    // lo + mid 2^32 + top 2^64 + offset, word by word
+    const u64 a0 = (u64)lo32(lo) + o0;
+    const u64 a1 = (u64)hi32(lo) + lo32(mid) + o1 + hi32(a0);
+    const u64 a2 = (u64)hi32(mid) + lo32(top) + o2 + hi32(a1);
+    u32 w0 = lo32(a0), w1 = lo32(a1), w2 = lo32(a2);
+    const u32 w3 = hi32(top) + o3 + hi32(a2);
+    if (folds) {
+      fold_words(w0, w1, w2, w3, fc, fs, fmask);
+      fold_words(w0, w1, w2, 0, fc, fs, fmask);
+      return csub(fold_mod(make64(w0, w1), fc, fs, fmask), q.q);
+    }
+    return reduce128_wide(make64(w2, w3), make64(w0, w1), q);
+  }
+};
 
 constexpr int kPwLdsBytes = 3 * (2048 + 1024) * 16;   // 144 KiB: three buffers of 2 weight digits (two of 3 fit too)
 __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ u8, const uint4 *__restrict__ w8,
@@ -727,21 +812,27 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
                                                       u64 *__restrict__ acc, int M, int KC, int n_live, size_t S,
                                                       int logN, const DevMod *__restrict__ mods,
                                                       const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
-                                                      const u64 *__restrict__ wl, int Mpad, int Cpad, PwItems items, PwLift lift) {
+                                                      const u64 *__restrict__ wl, int Mpad, int Cpad, PwItems items, PwLift lift,
+                                                      PwSwitch sw) {
   extern __shared__ uint4 pw_lds[];
   const u32 fl = *flag;
   const int G = (int)gridDim.x;
   if (fl & 1u) {                        // weights of 2^20 and more: the lifted form (rare), 128 filters per item
     const int MT = (M + 127) >> 7;
     for (int idx = blockIdx.x; idx < n_live * MT; idx += G)
-      pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)live[idx / MT] * 64, idx % MT, lift);
+      if (items.paired)   // n_live counts pairs; the pair's second tile is the limb-0 one
+        pw_general_pair(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)live[2 * (idx / MT) + 1] * 64,
+                        idx % MT, lift, sw);
+      else
+        pw_general_tile(image, chan, wl, acc, M, Mpad, Cpad, S, logN, mods, (size_t)live[idx / MT] * 64, idx % MT, lift);
     return;
   }
   const int nA = (fl & 2u) ? 3 : 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int N = 1 << logN;
-  const size_t cols = S * 4 * N;
+  const size_t cols = items.paired ? S * 2 * N : S * 4 * N;
+  const int KCB = items.paired ? 2 * KC : KC;   // steps of an item's column digits (paired: limb 1, then limb 0)
   const int stride = 2048 + 512 * nA, nbuf = nA == 2 ? 3 : 2;   // uint4 per buffer: column digits, weight digits
   const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) void *)pw_lds;
   // item index -> column-tile slot and first filter; false past the layer's last filter (pieces of the last block)
@@ -779,7 +870,7 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
   auto stager_item = [&]() {
     int slot, fb, f;
     if (s_it < items.n_items && decode(s_it, slot, fb, f)) {
-      gB = u8 + (size_t)slot * KC * 2048 + lane;
+      gB = u8 + (size_t)slot * KCB * 2048 + lane;   // (a pair's two tiles are adjacent slots of the digit image)
       gA = w8 + (size_t)(fb >> 7) * KC * 1536 + lane;
     }
   };
@@ -789,12 +880,13 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
     const u32 unit0 = (u32)(s_buf * stride) / 64;
 #pragma unroll
     for (int r = 0; r < 4; ++r) glds16(gB + (size_t)s_kc * 2048 + (wave * 4 + r) * 64, unit0 + wave * 4 + r);
+    const int a_kc = s_kc >= KC ? s_kc - KC : s_kc;   // the weights are the same for both limbs
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-      if (a < nA) glds16(gA + (size_t)s_kc * 1536 + (a * 8 + wave) * 64, unit0 + 32 + a * 8 + wave);
+      if (a < nA) glds16(gA + (size_t)a_kc * 1536 + (a * 8 + wave) * 64, unit0 + 32 + a * 8 + wave);
     ++staged;
     s_buf = s_buf + 1 == nbuf ? 0 : s_buf + 1;
-    if (++s_kc == KC) {
+    if (++s_kc == KCB) {
       s_kc = 0, s_it = next_item(s_it + G);
       stager_item();
     }
@@ -804,19 +896,39 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
   for (int c_it = next_item((int)blockIdx.x); c_it < items.n_items; c_it = next_item(c_it + G)) {
     int slot, fb, f;
     decode(c_it, slot, fb, f);
-    const int tile = live[slot];
+    const int tile = live[items.paired ? 2 * slot + 1 : slot];     // paired: the limb-0 tile, which names the output
     const int msn = f >> 5;                                       // 16-filter tiles per wave: 4, 2 or 1
     const int wfb = fb + wm * (f >> 1);                           // this wave's first filter
     const int u0 = __builtin_amdgcn_readfirstlane(((fb & 127) >> 4) + wm * msn);   // ... its unit in the 128-filter block
     // tiles of this wave that hold a filter at all (wave-uniform; fewer only in the layer's last block)
     const int ms_used = __builtin_amdgcn_readfirstlane(min(msn, max(0, (M - wfb + 15) / 16)));
-    const int nj = (items.skip7 >> (((size_t)tile * 64 >> logN) & 1)) & 1 ? 7 : 8;   // column digits with products
+    int nj = (items.skip7 >> (items.paired ? 1 : (int)(((size_t)tile * 64 >> logN) & 1))) & 1 ? 7 : 8;   // column digits with products
     v4i sum[4][10];
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
       for (int d = 0; d < 10; ++d) sum[ms][d] = v4i{1 << 28, 1 << 28, 1 << 28, 1 << 28};
-    for (int kc = 0; kc < KC; ++kc) {
+    for (int kc = 0; kc < KCB; ++kc) {
+      if (items.paired && kc == KC) {
+        // Limb 1 is complete: last = [a1 + q1/2]_q1 of every output, and limb 0's sums start at -last, digit by
+        // digit (they are plain integers), so that the second half accumulates a0 - last: nothing is parked.
+        const PwRed red(mods[1]);
+        const u64 q1 = mods[1].q;
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (ms >= ms_used) continue;
+            u32 p[10];
+#pragma unroll
+            for (int d = 0; d < 10; ++d) p[d] = (u32)sum[ms][d][r];
+            const u64 last = pw_switch_last(red(p), q1, sw);
+#pragma unroll
+            for (int d = 0; d < 10; ++d)
+              sum[ms][d][r] = (1 << 28) - (d < 8 ? (int)((last >> (8 * d)) & 255) : 0);
+          }
+        nj = items.skip7 & 1 ? 7 : 8;
+      }
       // This step has landed (this wave's copies; the barrier covers the others'), a later step may stay in flight:
       // when one was copied after it, at least 4 + nA operations are younger than this step's copies (an epilogue's
       // stores may be too, which only makes the wait longer).  Past the barrier every wave is done with the buffer of
@@ -855,28 +967,12 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
       }
     }
     const size_t c0 = (size_t)tile * 64;
-    const size_t col = c0 + wn * 16 + (lane & 15);
     const int mrow = wfb + (lane >> 4) * 4;   // + 16*ms + r
-    const DevMod q = mods[(int)((c0 >> logN) & 1)];
-    // value = sum_d (sum[d] - 2^28) 256^d, signed, below 2^100 in magnitude.  Assemble the biased digits into
-    // 128 bits, add k*q - bias (k*q in [2^101, 2^102)) to land on a non-negative representative below 2^103,
-    // then reduce: two folds of q = 2^b - c where the modulus has that shape, else Barrett.
-    const u32 qbits = 64 - (u32)__builtin_clzll(q.q), sh = 102 - qbits;   // q << sh in [2^101, 2^102)
-    const u64 kq_lo = q.q << sh, kq_hi = q.q >> (64 - sh);
-    const u64 off_lo = kq_lo - 0x1010101010000000ull, off_hi = kq_hi - 0x1010101010ull - (kq_lo < 0x1010101010000000ull);
-    const u32 fbits = q.fold_shift + 32, fc = q.fold_c;
-    // fold bounds: x < 2^103 -> x1 < 2^b + 2^(103-b) c (bits1 bits) -> x2 < 2^b + (x1 >> b) c (bits2 bits, must fit a word)
-    bool folds = fc != 0 && fbits >= 40 && fbits <= 62;
-    if (folds) {
-      const u32 cb = 32 - (u32)__builtin_clz(fc);
-      const u32 bits1 = max(fbits, 103 - fbits + cb) + 1;
-      const u32 bits2 = max(fbits, bits1 - fbits + cb) + 1;
-      folds = bits1 <= 64 + fbits && bits2 <= 64;
-    }
-    // (the epilogue is written on 32-bit words with v_mad_u64_u32 and funnel shifts; hipcc's 64-bit shifts by a
-    // register amount and its 128-bit adds made it a tenth of the kernel)
-    const u32 o0 = lo32(off_lo), o1 = hi32(off_lo), o2 = lo32(off_hi), o3 = hi32(off_hi);
-    const u32 fs = q.fold_shift, fmask = q.fold_mask;
+    const DevMod &q = mods[(int)((c0 >> logN) & 1)];
+    const PwRed red(q);
+    // paired: the limb-0 tile's (window, component, coefficient) in the one-limb layout [S][2][N]
+    const size_t col = (items.paired ? (((c0 >> (logN + 2)) * 2 + ((c0 >> (logN + 1)) & 1)) << logN) + (c0 & (size_t)(N - 1)) : c0) +
+                       wn * 16 + (lane & 15);
     u64 *__restrict__ out = acc + (size_t)mrow * cols + col;
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms)
@@ -886,23 +982,8 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
         u32 p[10];
 #pragma unroll
         for (int d = 0; d < 10; ++d) p[d] = (u32)sum[ms][d][r];
-        const u64 lo = mad32(p[3], 1u << 24, mad32(p[2], 1u << 16, mad32(p[1], 1u << 8, p[0])));
-        const u64 mid = mad32(p[7], 1u << 24, mad32(p[6], 1u << 16, mad32(p[5], 1u << 8, p[4])));
-        const u64 top = mad32(p[9], 1u << 8, p[8]);
-        // lo + mid 2^32 + top 2^64 + offset, word by word
-        const u64 a0 = (u64)lo32(lo) + o0;
-        const u64 a1 = (u64)hi32(lo) + lo32(mid) + o1 + hi32(a0);
-        const u64 a2 = (u64)hi32(mid) + lo32(top) + o2 + hi32(a1);
-        u32 w0 = lo32(a0), w1 = lo32(a1), w2 = lo32(a2);
-        const u32 w3 = hi32(top) + o3 + hi32(a2);
-        u64 v;
-        if (folds) {
-          fold_words(w0, w1, w2, w3, fc, fs, fmask);
-          fold_words(w0, w1, w2, 0, fc, fs, fmask);
-          v = csub(fold_mod(make64(w0, w1), fc, fs, fmask), q.q);
-        } else {
-          v = reduce128_wide(make64(w2, w3), make64(w0, w1), q);
-        }
+        u64 v = red(p);
+        if (items.paired) v = pw_switch_finish(v, q.q, sw);   // v was (a0 - last) mod q0
         if (mrow + 16 * ms + r < M) out[(size_t)(16 * ms + r) * cols] = v;
       }
   }
@@ -921,6 +1002,27 @@ static bool pw_use_mfma() {  // MMH_CONV_PW_MFMA=0 keeps the fast form on the ve
 // (the product's epilogue needs moduli of at least 40 bits for its k*q offset; SEAL's are 49 and 60)
 static bool pw_mfma_enabled(const mmh_ctx *ctx) {
   return pw_use_mfma() && (ctx->q[0] >> 39) != 0 && (ctx->q[1] >> 39) != 0;
+}
+// The product can hand the tail the mod-switched accumulator (paired items) when the last modulus is the smaller one
+// (its residue is then its own representative modulo q0, as ReshareCoeff::switched_plus assumes for qlast_small).
+// MMH_PW_PAIRED=0 keeps the two-limb accumulator (A/B measurements, tests of both forms).
+static bool pw_switched_ok(const mmh_ctx *ctx) {
+  const char *e = getenv("MMH_PW_PAIRED");
+  return !(e && e[0] == '0') && pw_mfma_enabled(ctx) && ctx->L == 2 && ctx->q[1] < ctx->q[0];
+}
+// Paired items are twice as long and half as many, so a layer needs enough of them to keep filling the chip: with
+// fewer than two rounds of n_cu paired items the product loses more to its last round (and to the smaller pieces that
+// round is cut into) than the tail gains from reading one word instead of two.  Measured, paired against single-limb
+// items, whole layer call: 256 -> 1024 1x1 at 14x14 (552 paired items) -3.7 %, 512 -> 1024 stride 2 -2.5 %,
+// 512 -> 2048 1x1 at 7x7 -1.3 %; 256 -> 256 3x3 at 14x14 (138 paired items, one round of double length against 1.25
+// rounds) +13.8 %, 64 -> 64 3x3 at 56x56 (125) +9 %.  In the kernels: the tail 87.7 -> 80.0 us per 1024 output
+// ciphertexts, the product unchanged at 69-70 us although it writes half the bytes.
+// MMH_PW_PAIRED=1 pairs every layer (tests), =0 none.
+static bool pw_paired_pays(const mmh_conv_plan *p) {
+  const char *e = getenv("MMH_PW_PAIRED");
+  if (e && e[0] == '1') return true;
+  const int n_live = (int)p->pw_live_tiles, M = (int)p->meta.n_filters, n_cu = p->ctx->n_cu;
+  return pw_items(n_live / 2, M, n_cu).n_items >= 2 * n_cu;
 }
 static PwSizes pw_sizes(const mmh_conv_plan *p) {
   PwSizes z;
@@ -955,9 +1057,11 @@ static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, c
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
                              const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1,
                              const u32 *nzmap = nullptr, u32 *zero_filter = nullptr, const PwFold *fold = nullptr,
-                             void *verdict_event = nullptr, const u64 *raw_filters = nullptr) {
+                             void *verdict_event = nullptr, const u64 *raw_filters = nullptr, bool switched = false) {
+  // switched: acc receives the MOD-SWITCHED product, [M][S][2][N] at the last level (pw_switched_ok() must hold)
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
+  MMH_REQUIRE(!switched || (pw_switched_ok(ctx) && form != 1 && !fill_dead), MMH_ERR_INTERNAL);
   const PwSizes z = pw_sizes(p);
   // live column tiles: all of c1, of c0 only those with a kept coefficient (about n_targets / 64 per limb)
   const size_t live_tiles = S * (2 * N / 64) + 2 * (p->n_targets / 64 + S);
@@ -982,12 +1086,16 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
                        p->d_pw_live, (uint4 *)u8, flag, KC, S, ctx->logN, nzmap, z.M, zero_filter,
                        fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0}, skip7);
     if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
-    PwItems items = pw_items(n_live, z.M, ctx->n_cu);
+    const int n_col = switched ? n_live / 2 : n_live;   // column tiles of the items: pairs or single tiles
+    PwItems items = pw_items(n_col, z.M, ctx->n_cu);
     items.skip7 = skip7;
+    items.paired = switched ? 1 : 0;
+    const u64 q0 = ctx->q[0], q1 = ctx->q[1];
+    const PwSwitch sw{ctx->bfv.inv_qlast_mod_q0, shoup(ctx->bfv.inv_qlast_mod_q0, q0), q1 >> 1, (q1 >> 1) % q0};
     hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
-                       (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_live, S, ctx->logN,
+                       (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_col, S, ctx->logN,
                        ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items,
-                       PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr});
+                       PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr}, sw);
     (void)scratch_free(u8, s);
   }
   // (on the matrix-core path the product kernel carries the lifted-weight form as a branch of its own)
@@ -1165,12 +1273,17 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     }
     // 64-column tiles (spatial window, c0/c1, limb, 64 coefficients) the product has to compute: all of c1, of
     // c0 those holding a kept coefficient
+    // (listed in pairs -- the limb-1 tile, then the limb-0 tile of the same 64 coefficients -- so that an item of
+    // the product kernel can own both limbs, PwItems::paired; the digit image follows this order)
     std::vector<int> live_tiles;
     for (size_t b = 0; b < p->n_spatial * 4 * (size_t)N / 64; ++b) {
       const size_t sp_i = (b * 64) / (4 * (size_t)N), pl = ((b * 64) / (size_t)N) & 3, i0 = (b * 64) % (size_t)N;
+      if (pl & 1) continue;   // limb-0 tiles name the pairs
       bool live = pl >= 2;
       for (size_t i = 0; i < 64 && !live; ++i) live = keep[sp_i * N + i0 + i] != 0;
-      if (live) live_tiles.push_back((int)b), ++p->pw_live_tiles_limb[pl & 1];
+      if (!live) continue;
+      live_tiles.push_back((int)(b + (size_t)N / 64)), live_tiles.push_back((int)b);
+      ++p->pw_live_tiles_limb[0], ++p->pw_live_tiles_limb[1];
     }
     p->pw_live_tiles = live_tiles.size();
     p->pw_taps_padded = chan.size();
@@ -1423,13 +1536,16 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && !direct) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
+  // The approximate tail's first act on the accumulator is divide_and_round_q_last: where the matrix-core product
+  // runs, its items own both limbs and write the switched value, one word per coefficient instead of two
+  const bool sw_acc = !exact && direct && pw_switched_ok(ctx) && (prepared ? prepared->form != 1 : front) && pw_paired_pays(p);
   if (!rc && direct && prepared)
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
-                           (u64 *)acc, s, exact, prepared->form);
+                           (u64 *)acc, s, exact, prepared->form, nullptr, nullptr, nullptr, nullptr, nullptr, sw_acc);
   if (!rc && front && !prepared)
     rc = pointwise_product(p, (const u64 *)image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8,
                            (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold,
-                           nz_inline ? verdict_event : nullptr, d_filters_raw);
+                           nz_inline ? verdict_event : nullptr, d_filters_raw, sw_acc);
   if (!rc && direct && !prepared && !front)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
   if (!rc && !direct && !prepared && d_filters_raw)
@@ -1446,10 +1562,10 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
     rc = d_zero_enc
              ? reshare_tail_online(ctx, (u64 *)acc, !direct, p->n_out, d_zero_enc, d_e1, d_mask, p->d_keep, S, d_out_cts,
-                                   s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share)
+                                   s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share, sw_acc)
              : reshare_tail_approx_u(ctx, (u64 *)acc, !direct, p->n_out, d_pk_ntt_last, d_u, (const u64 *)u_ntt, d_e1,
                                      d_mask, p->d_keep, S, d_out_cts, s, p->d_share_dst,
-                                     (size_t)(p->out_h * p->out_w), d_out_share);
+                                     (size_t)(p->out_h * p->out_w), d_out_share, sw_acc);
   }
   if (exact) {
     // USE_APPROX_RESHARE=0: uniform noise on c0 first, e0 kept, the mask is a plaintext mod t subtracted

@@ -286,6 +286,9 @@ struct ReshareSink {
   // of a power-of-two ring t*gamma mod q0 and -q0^-1 mod gamma (fast = 1; else the general behz_round)
   u64 inv_qlast_sh, sh_c, sh_c_sh, sh_ng, sh_ng_sh;
   int fast, qlast_small;
+  // acc is [n][2][N]: the accumulator after divide_and_round_q_last, canonical mod q0 (the matrix-core product's paired
+  // items, conv.hip, write it so), instead of [n][2][2][N] at the first level
+  int acc_switched;
 };
 // The tail's arithmetic on one coefficient (shared by the fused kernel's Emitter and the element-wise kernel):
 // divide_and_round_q_last of the accumulator, + the encryption of zero, then e1 (c1) or - mask (c0), truncation.
@@ -313,6 +316,17 @@ struct ReshareCoeff {
     const u64 y = shoup_mad_uniform(zz + add, x, f.inv_qlast, f.inv_qlast_sh, q0.nq);   // < 2 q0 + 3 q0
     if (q0.fold_c) return csub(fold_mod(y, q0.fold_c, q0.fold_shift, q0.fold_mask), q0.q);
     return csub(csub(csub(y, 4 * q0.q), 2 * q0.q), q0.q);
+  }
+  // the same from the switched accumulator ms = ((a0 - last + half0) q1^-1) mod q0: the same residue, one reduction
+  __device__ __forceinline__ u64 switched_plus(u64 ms, u64 zz, u64 add) const {
+    return csub(csub(ms + zz + add, 2 * q0.q), q0.q);   // three canonical terms (add <= q0)
+  }
+  __device__ __forceinline__ u64 c1_sw(u64 ms, u64 zz, int64_t e) const {
+    return switched_plus(ms, zz, signed_to_mod(e, q0.q)) & f.mask1;
+  }
+  __device__ __forceinline__ u64 c0_sw(u64 ms, u64 zz, u64 m, bool kept) const {
+    const u64 r = switched_plus(ms, zz, q0.q - m) & f.mask0;
+    return kept ? r : 0;
   }
   __device__ __forceinline__ u64 c1(u64 a0, u64 a1, u64 zz, int64_t e) const {
     return switched_plus(a0, a1, zz, signed_to_mod(e, q0.q)) & f.mask1;
@@ -363,7 +377,9 @@ struct Emitter {
     const u64 *z = lds + pad(t);  // coefficient k*256 + t at z[17 * 16 * k]
     constexpr int ZS = 256 + 16;
     const ReshareCoeff rc(f, mods);
-    const u64 *__restrict__ acc0 = f.acc + (((p * 2 + j) * 2) << LOGN), *__restrict__ acc1 = acc0 + (size_t(1) << LOGN);
+    const bool sw = f.acc_switched != 0;   // uniform over the launch
+    const u64 *__restrict__ acc0 = f.acc + (sw ? (p * 2 + j) << LOGN : ((p * 2 + j) * 2) << LOGN);
+    const u64 *__restrict__ acc1 = acc0 + (size_t(1) << LOGN);   // (not read when switched)
     u64 *__restrict__ dst = f.out + ((p * 2 + j) << LOGN);
     if (j == 1) {
       const int64_t *__restrict__ e1 = f.e1 ? f.e1 + (p << LOGN) : nullptr;
@@ -374,10 +390,11 @@ struct Emitter {
 #pragma unroll
         for (int k = 0; k < H; ++k) {
           const int i = (h + k) * 256 + t;
-          a0[k] = acc0[i], a1[k] = acc1[i], e[k] = e1 ? e1[i] : 0;
+          a0[k] = acc0[i], a1[k] = sw ? 0 : acc1[i], e[k] = e1 ? e1[i] : 0;
         }
 #pragma unroll
-        for (int k = 0; k < H; ++k) dst[(h + k) * 256 + t] = rc.c1(a0[k], a1[k], z[(h + k) * ZS], e[k]);
+        for (int k = 0; k < H; ++k)
+          dst[(h + k) * 256 + t] = sw ? rc.c1_sw(a0[k], z[(h + k) * ZS], e[k]) : rc.c1(a0[k], a1[k], z[(h + k) * ZS], e[k]);
       }
       return;
     }
@@ -399,12 +416,13 @@ struct Emitter {
 #pragma unroll
       for (int k = 0; k < H; ++k) {  // of removed c0 coefficients nothing more is read
         const int i = (h + k) * 256 + t;
-        a0[k] = kept[k] ? acc0[i] : 0, a1[k] = kept[k] ? acc1[i] : 0;
+        a0[k] = kept[k] ? acc0[i] : 0, a1[k] = kept[k] && !sw ? acc1[i] : 0;
       }
 #pragma unroll
       for (int k = 0; k < H; ++k) {
         if (d[k] >= 0) share[d[k]] = rc.share(m[k]);
-        dst[(h + k) * 256 + t] = rc.c0(a0[k], a1[k], z[(h + k) * ZS], m[k], kept[k]);
+        dst[(h + k) * 256 + t] = sw ? rc.c0_sw(a0[k], z[(h + k) * ZS], m[k], kept[k])
+                                    : rc.c0(a0[k], a1[k], z[(h + k) * ZS], m[k], kept[k]);
       }
     }
   }
@@ -472,7 +490,14 @@ __global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void ntt_inv_kernel(u64 *_
   constexpr int N = 1 << LOGN, RA = LOGN - 8, EA = 1 << RA, REPS = N / 4096;
   extern __shared__ __align__(16) u64 lds[];
   const int t = threadIdx.x;
-  const unsigned unit = limb_major_unit(limbs);
+  unsigned unit = limb_major_unit(limbs);
+  if (SINK == SINK_RESHARE) {
+    // Both components of an output ciphertext read the same u: workgroups go to the eight XCDs in turn, so units b
+    // and b + 8 share an L2 -- give them to the two components of one ciphertext (groups of 16 units; a last partial
+    // group keeps the plain order).
+    const unsigned b = blockIdx.x, full = gridDim.x & ~15u;
+    if (b < full) unit = (((b >> 4) << 3) + (b & 7)) * 2 + ((b >> 3) & 1);
+  }
   const DevMod &M = mods[mod_base + unit % limbs];
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset + N;
   u64 *__restrict__ a = data + (size_t)unit * N;
@@ -483,12 +508,22 @@ __global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void ntt_inv_kernel(u64 *_
         reinterpret_cast<const ulonglong2 *>(src.p + (((kj >> 1) * limbs + l) << LOGN));
     const ulonglong2 *__restrict__ key =
         reinterpret_cast<const ulonglong2 *>(src.p2 + (((kj & 1) * limbs + l) << LOGN));
+    if (FOLD && mul_mod_fold_ok(M)) {   // uniform over the workgroup
 #pragma unroll
-    for (int k = 0; k < N / 512; ++k) {
-      const int j = 2 * (k * 256 + t);
-      const ulonglong2 v = in[k * 256 + t], w = key[k * 256 + t];
-      lds[pad(j)] = mul_mod(v.x, w.x, M);
-      lds[pad(j) + 1] = mul_mod(v.y, w.y, M);
+      for (int k = 0; k < N / 512; ++k) {
+        const int j = 2 * (k * 256 + t);
+        const ulonglong2 v = in[k * 256 + t], w = key[k * 256 + t];
+        lds[pad(j)] = mul_mod_fold(v.x, w.x, M);
+        lds[pad(j) + 1] = mul_mod_fold(v.y, w.y, M);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < N / 512; ++k) {
+        const int j = 2 * (k * 256 + t);
+        const ulonglong2 v = in[k * 256 + t], w = key[k * 256 + t];
+        lds[pad(j)] = mul_mod(v.x, w.x, M);
+        lds[pad(j) + 1] = mul_mod(v.y, w.y, M);
+      }
     }
   } else {
     const ulonglong2 *__restrict__ in = reinterpret_cast<const ulonglong2 *>(a);
@@ -560,11 +595,12 @@ __global__ __launch_bounds__(256) void reshare_elem_kernel(const u64 *__restrict
   const size_t unit = idx >> logN, p = unit >> 1;
   const int i = (int)(idx & ((size_t(1) << logN) - 1)), j = (int)(unit & 1);
   const ReshareCoeff rc(f, mods);
-  const size_t a = (((p * 2 + j) * 2) << logN) + i;
+  const bool sw = f.acc_switched != 0;
+  const size_t a = sw ? idx : (((p * 2 + j) * 2) << logN) + i;
   const u64 zz = zero[idx];
   if (j == 1) {
     const int64_t e = f.e1 ? f.e1[(p << logN) + i] : 0;
-    f.out[idx] = rc.c1(f.acc[a], f.acc[a + (size_t(1) << logN)], zz, e);
+    f.out[idx] = sw ? rc.c1_sw(f.acc[a], zz, e) : rc.c1(f.acc[a], f.acc[a + (size_t(1) << logN)], zz, e);
     return;
   }
   const size_t kp = ((p % f.keep_period) << logN) + i;
@@ -572,8 +608,8 @@ __global__ __launch_bounds__(256) void reshare_elem_kernel(const u64 *__restrict
   const int d = f.share_dst ? f.share_dst[kp] : -1;
   const u64 m = f.mask[(p << logN) + i];
   if (d >= 0) f.share_out[(p / f.keep_period) * f.share_plane + d] = rc.share(m);
-  const u64 a0 = kept ? f.acc[a] : 0, a1 = kept ? f.acc[a + (size_t(1) << logN)] : 0;
-  f.out[idx] = rc.c0(a0, a1, zz, m, kept);
+  const u64 a0 = kept ? f.acc[a] : 0, a1 = kept && !sw ? f.acc[a + (size_t(1) << logN)] : 0;
+  f.out[idx] = sw ? rc.c0_sw(a0, zz, m, kept) : rc.c0(a0, a1, zz, m, kept);
 }
 
 
@@ -705,11 +741,11 @@ int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *
 
 static ReshareSink make_sink(const mmh_ctx *ctx, const u64 *d_acc, const int64_t *d_e1, const u64 *d_mask, u64 *d_out,
                              const uint8_t *d_keep, size_t keep_period, const int *d_share_dst, size_t share_plane,
-                             u64 *d_share_out) {
+                             u64 *d_share_out, bool acc_switched) {
   const BfvConsts &b = ctx->bfv;
   const u64 q0 = ctx->q[0], g = b.gamma.q;
   ReshareSink f{d_acc, d_e1, d_mask, d_out, b.inv_qlast_mod_q0, b.mask0, b.mask1, d_keep, keep_period ? keep_period : 1,
-                d_share_dst, share_plane, d_share_out, b, 0, 0, 0, 0, 0, 0, 0};
+                d_share_dst, share_plane, d_share_out, b, 0, 0, 0, 0, 0, 0, 0, acc_switched ? 1 : 0};
   f.inv_qlast_sh = shoup(b.inv_qlast_mod_q0, q0);
   f.qlast_small = ctx->L == 2 && ctx->q[1] < q0;
   // last level: one limb, Q = q0, so inv_punct = punct = 1
@@ -724,21 +760,24 @@ static ReshareSink make_sink(const mmh_ctx *ctx, const u64 *d_acc, const int64_t
 int ntt_inv_product_reshare(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, size_t n, const u64 *d_acc,
                             const int64_t *d_e1, const u64 *d_mask, u64 *d_out, const uint8_t *d_keep,
                             size_t keep_period, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
-                            hipStream_t s) {
+                            hipStream_t s, bool acc_switched) {
   NttSource src{};
   src.p = d_u_ntt, src.p2 = d_key;
-  const ReshareSink fin = make_sink(ctx, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst, share_plane, d_share_out);
+  const ReshareSink fin = make_sink(ctx, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst, share_plane, d_share_out,
+                                    acc_switched);
   return dispatch(ctx, -3, d_out, src, n * 2, 1, 0, s, &fin);
 }
 
 // The same tail from an encryption of zero in memory, d_zero [n][2][N] (coefficient form at the last level).
 int reshare_online_dispatch(const mmh_ctx *ctx, const u64 *d_zero, size_t n, const u64 *d_acc, const int64_t *d_e1,
                             const u64 *d_mask, u64 *d_out, const uint8_t *d_keep, size_t keep_period,
-                            const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s) {
+                            const int *d_share_dst, size_t share_plane, u64 *d_share_out, hipStream_t s,
+                            bool acc_switched) {
   if (n == 0) return MMH_OK;
   const size_t total = (n * 2) << ctx->logN;
   MMH_REQUIRE((total + 255) / 256 <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
-  const ReshareSink fin = make_sink(ctx, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst, share_plane, d_share_out);
+  const ReshareSink fin = make_sink(ctx, d_acc, d_e1, d_mask, d_out, d_keep, keep_period, d_share_dst, share_plane, d_share_out,
+                                    acc_switched);
   hipLaunchKernelGGL(reshare_elem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_zero, ctx->d_mods, fin,
                      ctx->logN, total);
   MMH_HIP(hipGetLastError());
