@@ -8,6 +8,7 @@
 #include "host_math.hpp"
 #include "ntt_device.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace mmh {
@@ -807,14 +808,28 @@ struct PwRed {
 };
 
 constexpr int kPwLdsBytes = 3 * (2048 + 1024) * 16;   // 144 KiB: three buffers of 2 weight digits (two of 3 fit too)
+// STAMPS (diagnostic instantiation, MMH_PW_STAMPS=<file>): lane 0 of every wave of workgroup 0 records the shader clock
+// at five points of each of its first kPwStampSteps steps -- 0 top of the step, 1 past the wait and the barrier (this
+// step's digits have landed for every wave), 2 the next step's copies issued, 3 the fragments read (first product can
+// issue), 4 the last product issued -- into stamps[wave][step][5].  Reading the clock drains the scalar counter, so the
+// stamped kernel runs some per cent slower than the plain one; the table shows where a step's cycles go.
+constexpr int kPwStampSteps = 96;
+template <bool STAMPS>
 __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ u8, const uint4 *__restrict__ w8,
                                                       const u32 *__restrict__ flag, const int *__restrict__ live,
                                                       u64 *__restrict__ acc, int M, int KC, int n_live, size_t S,
                                                       int logN, const DevMod *__restrict__ mods,
                                                       const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
                                                       const u64 *__restrict__ wl, int Mpad, int Cpad, PwItems items, PwLift lift,
-                                                      PwSwitch sw) {
+                                                      PwSwitch sw, u64 *__restrict__ stamps) {
   extern __shared__ uint4 pw_lds[];
+  int stamp_step = 0;
+  auto stamp = [&](int k) {
+    if (STAMPS && blockIdx.x == 0 && stamp_step < kPwStampSteps) {
+      const u64 t = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) stamps[((threadIdx.x >> 6) * kPwStampSteps + stamp_step) * 5 + k] = t;
+    }
+  };
   const u32 fl = *flag;
   const int G = (int)gridDim.x;
   if (fl & 1u) {                        // weights of 2^20 and more: the lifted form (rare), 128 filters per item
@@ -929,6 +944,7 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
           }
         nj = items.skip7 & 1 ? 7 : 8;
       }
+      stamp(0);
       // This step has landed (this wave's copies; the barrier covers the others'), a later step may stay in flight:
       // when one was copied after it, at least 4 + nA operations are younger than this step's copies (an epilogue's
       // stores may be too, which only makes the wait longer).  Past the barrier every wave is done with the buffer of
@@ -940,7 +956,9 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      stamp(1);
       stage_next();   // (issuing the pieces between the groups of products instead measured the same)
+      stamp(2);
       const uint4 *ldsB = pw_lds + cur * stride, *ldsA = ldsB + 2048;
       cur = cur + 1 == nbuf ? 0 : cur + 1;
       ++done;
@@ -949,6 +967,10 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
       for (int j = 0; j < 8; ++j) {
         const uint4 t = ldsB[(j * 4 + wn) * 64 + lane];
         b[j] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+      }
+      if (STAMPS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(3);
       }
 #pragma unroll
       for (int ms = 0; ms < 4; ++ms) {
@@ -965,6 +987,8 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
           }
         }
       }
+      stamp(4);
+      if (STAMPS) ++stamp_step;
     }
     const size_t c0 = (size_t)tile * 64;
     const int mrow = wfb + (lane >> 4) * 4;   // + 16*ms + r
@@ -1092,10 +1116,39 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     items.paired = switched ? 1 : 0;
     const u64 q0 = ctx->q[0], q1 = ctx->q[1];
     const PwSwitch sw{ctx->bfv.inv_qlast_mod_q0, shoup(ctx->bfv.inv_qlast_mod_q0, q0), q1 >> 1, (q1 >> 1) % q0};
-    hipLaunchKernelGGL(pw_mfma_kernel, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
+    const char *stamp_file = getenv("MMH_PW_STAMPS");   // diagnostic: the stamped instantiation, its table appended to that file
+    if (stamp_file && stamp_file[0]) {
+      const size_t words = (size_t)8 * kPwStampSteps * 5;
+      u64 *d_st = nullptr;
+      MMH_HIP(hipMalloc((void **)&d_st, words * 8));
+      MMH_HIP(hipMemsetAsync(d_st, 0, words * 8, s));
+      MMH_HIP(hipFuncSetAttribute((const void *)pw_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes));
+      hipLaunchKernelGGL(pw_mfma_kernel<true>, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
+                         (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_col, S, ctx->logN,
+                         ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items,
+                         PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr}, sw, d_st);
+      std::vector<u64> h(words);
+      MMH_HIP(hipMemcpyAsync(h.data(), d_st, words * 8, hipMemcpyDeviceToHost, s));
+      MMH_HIP(hipStreamSynchronize(s));
+      (void)hipFree(d_st);
+      if (FILE *f = fopen(stamp_file, "a")) {
+        fprintf(f, "# pw_mfma_kernel stamps: M=%d KC=%d items=%d paired=%d F=%d (workgroup 0; wave step t0 d1 d2 d3 d4: shader "
+                   "cycles from t0 to barrier passed / copies issued / fragments read / last product issued)\n",
+                z.M, KC, items.n_items, items.paired, 1 << items.F_log);
+        for (int w = 0; w < 8; ++w)
+          for (int st = 0; st < kPwStampSteps; ++st) {
+            const u64 *r = &h[((size_t)w * kPwStampSteps + st) * 5];
+            if (!r[0]) break;
+            fprintf(f, "%d %d %llu %lld %lld %lld %lld\n", w, st, (unsigned long long)r[0], (long long)(r[1] - r[0]),
+                    (long long)(r[2] - r[0]), (long long)(r[3] - r[0]), (long long)(r[4] - r[0]));
+          }
+        fclose(f);
+      }
+    } else
+    hipLaunchKernelGGL(pw_mfma_kernel<false>, dim3((unsigned)std::min(items.n_items, ctx->n_cu)), dim3(512), kPwLdsBytes, s,
                        (const uint4 *)u8, (const uint4 *)w8, flag, p->d_pw_live, acc, z.M, KC, n_col, S, ctx->logN,
                        ctx->d_mods, image, p->d_pw_chan, wl, z.Mpad, z.Cpad, items,
-                       PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr}, sw);
+                       PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr}, sw, (u64 *)nullptr);
     (void)scratch_free(u8, s);
   }
   // (on the matrix-core path the product kernel carries the lifted-weight form as a branch of its own)
@@ -1288,7 +1341,7 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     p->pw_live_tiles = live_tiles.size();
     p->pw_taps_padded = chan.size();
     // the product's two LDS buffers exceed the static 64 KiB: opt in (per device; plans are made on the context's)
-    if (hipFuncSetAttribute((const void *)pw_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) !=
+    if (hipFuncSetAttribute((const void *)pw_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) !=
         hipSuccess) {
       set_error("mmh_conv_plan_create: hipFuncSetAttribute failed");
       mmh_conv_plan_destroy(p);
