@@ -11,6 +11,9 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
                         const int64_t *d_u, const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep,
                         size_t keep_period, u64 *d_out, hipStream_t s, const int *d_share_dst, size_t share_plane,
                         u64 *d_share_out);
+int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs, int mod_base, hipStream_t s);
+int ntt_inv_product_each_dispatch(const mmh_ctx *ctx, const u64 *d_pt_ntt, const u64 *d_ct_ntt, const u64 *d_pt2_ntt,
+                                  const u64 *d_ct2_ntt, u64 *d_out, size_t n, int limbs, hipStream_t s);
 int launch_share_from_mask(const mmh_ctx *ctx, const u64 *r, u64 *out, size_t groups, size_t n_targets,
                            size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
                            hipStream_t s);
@@ -119,6 +122,56 @@ __global__ __launch_bounds__(256) void gather_f2r_pre_kernel(int party, const u6
   tmp[src] = v;
   msb[src] = m;
   if (party == kAlice && corr) corr[src] = m ? 0 : corr_value;
+}
+// HomBNSS chunking and BatchEncoder's slot order in one pass (encodeVector, hom_bn_ss.cc:203-233: chunk, zero pad,
+// BatchEncoder::encode's scatter and reduction mod t; the inverse transform follows)
+__global__ __launch_bounds__(256) void chunk_scatter_kernel(const u64 *__restrict__ vec, u64 *__restrict__ pts,
+                                                            size_t n_ct, size_t n, size_t sub_len, int logN,
+                                                            const u32 *__restrict__ map, ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_ct << logN)) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const size_t src = k * sub_len + i;
+  const u64 v = (i < sub_len && src < n) ? vec[src] : 0;
+  pts[(k << logN) + map[i]] = red_t2(v, t);
+}
+// addMask's r (hom_bn_ss.cc:333-340) straight into that slot order: r = random % p, share = -r mod p
+__global__ __launch_bounds__(256) void bn_mask_scatter_kernel(const u64 *__restrict__ random, u64 *__restrict__ pts,
+                                                              u64 *__restrict__ share, size_t n_ct, size_t n,
+                                                              size_t sub_len, int logN, const u32 *__restrict__ map,
+                                                              ModC t) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (n_ct << logN)) return;
+  const size_t k = idx >> logN, i = idx & ((size_t(1) << logN) - 1);
+  const size_t src = k * sub_len + i;
+  u64 v = 0;
+  if (i < sub_len && src < n) {
+    v = red_t2(random[src], t);
+    share[src] = v ? t.q - v : 0;
+  }
+  pts[(k << logN) + map[i]] = v;
+}
+// The rest of bn / bole per coefficient: mod_switch_to_inplace(last) of the product (hom_bn_ss.cc:269,:308), addMask's
+// add_plain_inplace of encode(r) at the last level (:355) and truncate_for_decryption (:357), one pass.
+// acc [n][2][2][N] coefficient form at the first level, rpts [n][N] mod t, out [n][2][N].
+__global__ __launch_bounds__(256) void bn_finish_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ rpts,
+                                                        u64 *__restrict__ out, size_t total, int logN, BfvConsts b,
+                                                        const DevMod *__restrict__ mods) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over [n*2][N]
+  if (idx >= total) return;
+  const size_t i = idx & ((size_t(1) << logN) - 1), p = idx >> logN;
+  const DevMod &q0 = mods[0];
+  const u64 q1 = mods[1].q, half = q1 >> 1;
+  const u64 last = csub(acc[((p * 2 + 1) << logN) + i] + half, q1);
+  const u64 tmp = sub_mod(reduce64(last, q0), reduce64(half, q0), q0.q);
+  u64 v = mul_mod(sub_mod(acc[((p * 2) << logN) + i], tmp, q0.q), b.inv_qlast_mod_q0, q0);
+  if ((p & 1) == 0) {
+    const u64 m = rpts[((p >> 1) << logN) + i];
+    if (m) v = add_mod(v, scaled_plain(m, scale_fix(m, b, b.lv[1]), b.lv[1].delta_mod_q[0], q0), q0.q);
+    out[idx] = v & b.mask0;
+  } else {
+    out[idx] = v & b.mask1;
+  }
 }
 // addMask (hom_bn_ss.cc:333-340): r = random % p in place, share = -r mod p
 __global__ __launch_bounds__(256) void bn_mask_kernel(const u64 *__restrict__ random, u64 *__restrict__ r,
@@ -368,15 +421,10 @@ extern "C" int mmh_bn_encode_vector(const mmh_ctx *ctx, const uint64_t *d_vec, s
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
   MMH_REQUIRE(d_vec && d_pts, MMH_ERR_NULL_POINTER);
   hipStream_t s = (hipStream_t)stream;
-  void *slots = nullptr;
-  MMH_HIP(scratch_alloc(&slots, (n_ct << ctx->logN) * 8, s));
-  int rc = MMH_OK;
-  hipLaunchKernelGGL(chunk_pad_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, d_vec, (u64 *)slots, n_ct, n,
-                     sub, ctx->logN);
-  if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
-  if (!rc) rc = mmh_batch_encode(ctx, (const u64 *)slots, n_ct, d_pts, stream);
-  (void)scratch_free(slots, s);
-  return rc;
+  hipLaunchKernelGGL(chunk_scatter_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, d_vec, d_pts, n_ct, n, sub,
+                     ctx->logN, ctx->d_slot_map, ctx->bfv.t);
+  MMH_HIP(hipGetLastError());
+  return ntt_dispatch(ctx, true, d_pts, n_ct, 1, (int)ctx->L, s);   // BatchEncoder::encode's inverse transform mod t
 }
 
 extern "C" int mmh_bn_encrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, const uint64_t *d_vec, size_t n,
@@ -397,21 +445,24 @@ extern "C" int mmh_bn_encrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
 // shared tail of bn / bole: mod-switch, addMask, truncate
 static int bn_tail(const mmh_ctx *ctx, const u64 *acc, size_t n, size_t n_ct, size_t sub, const u64 *d_random,
                    u64 *d_out_cts, u64 *d_out_share, hipStream_t s) {
-  void *r = nullptr, *rpts = nullptr;
-  int rc = mmh_mod_switch_to_last(ctx, acc, n_ct, d_out_cts, s);
-  if (!rc && scratch_alloc(&r, n * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
-  if (!rc && scratch_alloc(&rpts, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  // three launches: r and its share straight into slot order, BatchEncoder's inverse transform of r, and one pass that
+  // mod-switches the product, adds the scaled r and truncates (the step-by-step entry points give the same bits)
+  void *rpts = nullptr;
+  int rc = MMH_OK;
+  if (scratch_alloc(&rpts, (n_ct << ctx->logN) * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
   if (!rc) {
-    hipLaunchKernelGGL(bn_mask_kernel, dim3(nblk(n)), dim3(256), 0, s, d_random, (u64 *)r, d_out_share, n,
-                       ctx->bfv.t);
+    hipLaunchKernelGGL(bn_mask_scatter_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, d_random, (u64 *)rpts,
+                       d_out_share, n_ct, n, sub, ctx->logN, ctx->d_slot_map, ctx->bfv.t);
     if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
   }
-  if (!rc) rc = mmh_bn_encode_vector(ctx, (const u64 *)r, n, (u64 *)rpts, s);
-  if (!rc) rc = mmh_add_plain(ctx, 1, d_out_cts, (const u64 *)rpts, n_ct, 0, d_out_cts, s);
-  if (!rc) rc = mmh_truncate_and_zero(ctx, d_out_cts, n_ct, nullptr, 1, s);
-  if (r) (void)scratch_free(r, s);
+  if (!rc) rc = ntt_dispatch(ctx, true, (u64 *)rpts, n_ct, 1, (int)ctx->L, s);
+  if (!rc) {
+    const size_t total = n_ct * 2 * ctx->N;
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(total)), dim3(256), 0, s, acc, (const u64 *)rpts, d_out_cts, total,
+                       ctx->logN, ctx->bfv, ctx->d_mods);
+    if (hipGetLastError() != hipSuccess) rc = MMH_ERR_INTERNAL;
+  }
   if (rpts) (void)scratch_free(rpts, s);
-  (void)sub;
   return rc;
 }
 
@@ -425,20 +476,25 @@ extern "C" int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
   const size_t N = ctx->N;
-  void *sum = nullptr, *acc = nullptr;
+  void *sum = nullptr, *acc = nullptr, *pt_ntt = nullptr;
   int rc = MMH_OK;
-  const u64 *cts = d_in_cts;
-  if (d_share_pts) {  // hom_bn_ss.cc:263-265
-    MMH_HIP(scratch_alloc(&sum, n_ct * 4 * N * 8, s));
+  // hom_bn_ss.cc:263-265: the server's share added (out of place), or a working copy of the client's ciphertexts
+  MMH_HIP(scratch_alloc(&sum, n_ct * 4 * N * 8, s));
+  if (d_share_pts)
     rc = mmh_add_plain(ctx, 0, d_in_cts, d_share_pts, n_ct, 0, (u64 *)sum, stream);
-    cts = (const u64 *)sum;
-  }
+  else if (hipMemcpyAsync(sum, d_in_cts, n_ct * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    rc = MMH_ERR_INTERNAL;
   if (!rc && scratch_alloc(&acc, n_ct * 4 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
-  // :265-267: out[i] = cts[i] * scales[i]
-  if (!rc) rc = mmh_mul_plain_acc(ctx, 0, cts, n_ct, d_scale_pts, n_ct, 1, n_ct, 1, 0, 1, 0, 0, 1, (u64 *)acc, stream);
+  if (!rc && scratch_alloc(&pt_ntt, n_ct * 2 * N * 8, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  // :265-267: out[i] = cts[i] * scales[i] (multiply_plain): both operands to NTT form, the dyadic product formed while
+  // the inverse transform loads (same canonical values as mmh_mul_plain_acc's separate product pass)
+  if (!rc) rc = ntt_dispatch(ctx, false, (u64 *)sum, n_ct * 2, 2, 0, s);
+  if (!rc) rc = mmh_plain_lift_ntt(ctx, 0, d_scale_pts, n_ct, (u64 *)pt_ntt, stream);
+  if (!rc)
+    rc = ntt_inv_product_each_dispatch(ctx, (const u64 *)pt_ntt, (const u64 *)sum, nullptr, nullptr, (u64 *)acc, n_ct, 2, s);
   if (!rc) rc = bn_tail(ctx, (const u64 *)acc, n, n_ct, sub, d_random, d_out_cts, d_out_share, s);
-  if (sum) (void)scratch_free(sum, s);
-  if (acc) (void)scratch_free(acc, s);
+  for (void *b : {sum, acc, pt_ntt})
+    if (b) (void)scratch_free(b, s);
   return rc;
 }
 
@@ -451,13 +507,27 @@ extern "C" int mmh_bole_server(const mmh_ctx *ctx, const uint64_t *d_enc_xy, con
   MMH_REQUIRE(d_enc_xy && d_pts_yx && d_random && d_out_cts && d_out_share, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(ctx->L == 2, MMH_ERR_CONFIG);
   hipStream_t s = (hipStream_t)stream;
-  void *acc = nullptr;
-  MMH_HIP(scratch_alloc(&acc, n_ct * 4 * ctx->N * 8, s));
-  // hom_bn_ss.cc:304-306: out[i] = ex[i]*py[i] + ey[i]*px[i]; operands are [ex; ey] and [py; px]
-  int rc = mmh_mul_plain_acc(ctx, 0, d_enc_xy, 2 * n_ct, d_pts_yx, 2 * n_ct, 1, n_ct, 2, n_ct, 1, 0, n_ct, 1,
-                             (u64 *)acc, stream);
+  const size_t N = ctx->N;
+  void *acc = nullptr, *ct_ntt = nullptr, *pt_ntt = nullptr;
+  int rc = MMH_OK;
+  auto grab = [&](void **b, size_t bytes) {
+    if (!rc && scratch_alloc(b, bytes, s) != hipSuccess) rc = MMH_ERR_MEMORY;
+  };
+  grab(&acc, n_ct * 4 * N * 8);
+  grab(&ct_ntt, 2 * n_ct * 4 * N * 8);
+  grab(&pt_ntt, 2 * n_ct * 2 * N * 8);
+  // hom_bn_ss.cc:304-306: out[i] = ex[i]*py[i] + ey[i]*px[i]; operands are [ex; ey] and [py; px].  Both to NTT form,
+  // the two dyadic products and their sum formed while the inverse transform loads.
+  if (!rc && hipMemcpyAsync(ct_ntt, d_enc_xy, 2 * n_ct * 4 * N * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    rc = MMH_ERR_INTERNAL;
+  if (!rc) rc = ntt_dispatch(ctx, false, (u64 *)ct_ntt, 2 * n_ct * 2, 2, 0, s);
+  if (!rc) rc = mmh_plain_lift_ntt(ctx, 0, d_pts_yx, 2 * n_ct, (u64 *)pt_ntt, stream);
+  if (!rc)
+    rc = ntt_inv_product_each_dispatch(ctx, (const u64 *)pt_ntt, (const u64 *)ct_ntt, (const u64 *)pt_ntt + n_ct * 2 * N,
+                                       (const u64 *)ct_ntt + n_ct * 4 * N, (u64 *)acc, n_ct, 2, s);
   if (!rc) rc = bn_tail(ctx, (const u64 *)acc, n, n_ct, sub, d_random, d_out_cts, d_out_share, s);
-  (void)scratch_free(acc, s);
+  for (void *b : {acc, ct_ntt, pt_ntt})
+    if (b) (void)scratch_free(b, s);
   return rc;
 }
 
@@ -485,9 +555,6 @@ extern "C" int mmh_bn_decrypt_vector(const mmh_ctx *ctx, const uint64_t *d_sk_nt
 }
 
 // ---- conversions fused with the neighbouring vector step (same bits as the two calls they replace)
-namespace mmh {
-int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs, int mod_base, hipStream_t s);
-}
 extern "C" int mmh_bn_encode_vector_r2f(const mmh_ctx *ctx, int party, const uint64_t *d_tmp, const uint8_t *d_msb,
                                         const uint64_t *d_y, size_t n, int bw, uint64_t *d_pts, void *stream) {
   MMH_DEVICE_SCOPE(ctx);

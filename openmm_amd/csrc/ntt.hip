@@ -506,9 +506,23 @@ __global__ __launch_bounds__(256, LOGN == 12 ? 4 : 2) void ntt_inv_kernel(u64 *_
     const size_t kj = unit / limbs, l = unit % limbs;
     const ulonglong2 *__restrict__ in =
         reinterpret_cast<const ulonglong2 *>(src.p + (((kj >> 1) * limbs + l) << LOGN));
-    const ulonglong2 *__restrict__ key =
-        reinterpret_cast<const ulonglong2 *>(src.p2 + (((kj & 1) * limbs + l) << LOGN));
-    if (FOLD && mul_mod_fold_ok(M)) {   // uniform over the workgroup
+    const size_t kidx = ((src.p2_each ? kj : (kj & 1)) * limbs + l) << LOGN;
+    const ulonglong2 *__restrict__ key = reinterpret_cast<const ulonglong2 *>(src.p2 + kidx);
+    if (src.p3) {   // sum of two products (uniform over the launch)
+      const ulonglong2 *__restrict__ in2 =
+          reinterpret_cast<const ulonglong2 *>(src.p3 + (((kj >> 1) * limbs + l) << LOGN));
+      const ulonglong2 *__restrict__ key2 = reinterpret_cast<const ulonglong2 *>(src.p4 + kidx);
+      const bool fold = FOLD && mul_mod_fold_ok(M);
+#pragma unroll
+      for (int k = 0; k < N / 512; ++k) {
+        const int j = 2 * (k * 256 + t);
+        const ulonglong2 v = in[k * 256 + t], w = key[k * 256 + t], v2 = in2[k * 256 + t], w2 = key2[k * 256 + t];
+        lds[pad(j)] = add_mod(fold ? mul_mod_fold(v.x, w.x, M) : mul_mod(v.x, w.x, M),
+                              fold ? mul_mod_fold(v2.x, w2.x, M) : mul_mod(v2.x, w2.x, M), M.q);
+        lds[pad(j) + 1] = add_mod(fold ? mul_mod_fold(v.y, w.y, M) : mul_mod(v.y, w.y, M),
+                                  fold ? mul_mod_fold(v2.y, w2.y, M) : mul_mod(v2.y, w2.y, M), M.q);
+      }
+    } else if (FOLD && mul_mod_fold_ok(M)) {   // uniform over the workgroup
 #pragma unroll
       for (int k = 0; k < N / 512; ++k) {
         const int j = 2 * (k * 256 + t);
@@ -731,6 +745,15 @@ int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, si
   return dispatch(ctx, SRC_FILTER, d_out, src, n_filters * (size_t)n_cslices, limbs, 0, s);
 }
 
+// out[k][j][l] = INTT_l(pt_ntt[k][l] (.) ct_ntt[k][j][l] (+ pt2_ntt[k][l] (.) ct2_ntt[k][j][l])) for the first `limbs`
+// moduli: multiply_plain (and the sum of two) with the dyadic product formed while the inverse transform loads
+// (HomBNSS::bn, hom_bn_ss.cc:265-267; ::bole :304-306)
+int ntt_inv_product_each_dispatch(const mmh_ctx *ctx, const u64 *d_pt_ntt, const u64 *d_ct_ntt, const u64 *d_pt2_ntt,
+                                  const u64 *d_ct2_ntt, u64 *d_out, size_t n, int limbs, hipStream_t s) {
+  NttSource src{};
+  src.p = d_pt_ntt, src.p2 = d_ct_ntt, src.p3 = d_pt2_ntt, src.p4 = d_ct2_ntt, src.p2_each = 1;
+  return dispatch(ctx, -2, d_out, src, n * 2, limbs, 0, s);
+}
 // out[k][j][l] = INTT_l(u_ntt[k][l] (.) key[j][l]) for j = 0, 1 and the first `limbs` moduli
 int ntt_inv_product_dispatch(const mmh_ctx *ctx, const u64 *d_u_ntt, const u64 *d_key, u64 *d_out, size_t n,
                              int limbs, hipStream_t s) {

@@ -210,6 +210,11 @@ enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3 };
 struct NttSource {
   const u64 *p;
   const u64 *p2;                   // inverse transform of a product: the key pair [2][limbs][N] (p = [n][limbs][N])
+  // ... or, p2_each != 0, one second operand per output polynomial: p2 = [n][2][limbs][N] (ciphertexts in NTT form
+  // times their own plaintext p[k], HomBNSS::bn); p3 / p4 (or null): a second pair of the same shapes whose product is
+  // added before the transform (HomBNSS::bole: ex * py + ey * px)
+  const u64 *p3, *p4;
+  int p2_each;
   u64 t, thr;                      // plain modulus and the lift threshold (t + 1) / 2
   u64 t_bhi, t_blo;                // Barrett constants of t (SRC_FILTER reduces the raw weights)
   int C, taps, wc, n_cslices;      // channels, fh*fw, channels per slice, slices per filter
