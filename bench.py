@@ -463,7 +463,10 @@ class NetworkLegs:
 
     def conv_call(self, shape):
         meta, plan, cts, share, filters = self.conv_inputs(shape)
-        return lambda: self.srv.conv2DSSFromTensors(cts, share, filters, meta, self.draw(plan.n_out))
+        # (the zero-filter verdict of conv2DOneFilter is computed inside the call and read by srv.raise_pending() behind
+        # the caller's synchronisation, as the C++ host reads it behind the one it needs before the send: the host does
+        # not stop at every layer)
+        return lambda: self.srv.conv2DSSFromTensors(cts, share, filters, meta, self.draw(plan.n_out), defer_verdict=True)
 
     def fc_call(self, rows, cols):
         from openmm_amd.hom_fc_ss import Meta as FcMeta
@@ -557,26 +560,30 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=20, convs=Non
         """per-call wall time in steady state: the call repeated untimed for prewarm_s first (the same count on every
         rank: the sharded forms hold a collective), since an idle MI355X needs tens of ms of load to settle (timed()
         above; one layer call: 0.219 ms over 30 calls from idle, 0.199 over 300, 0.195 over 1000)"""
+        def drain():   # the stream's end, then the zero-filter verdicts of the calls behind it (inside the timed region)
+            torch.cuda.synchronize()
+            srv.raise_pending()
+
         fn()
         fn()   # warm-up: the scratch cache and torch's allocator have their blocks by now
-        torch.cuda.synchronize()
+        drain()
         if prewarm_s > 0:
             t0 = time.perf_counter()
             fn()
-            torch.cuda.synchronize()
+            drain()
             one = max(time.perf_counter() - t0, 1e-5)
             n = int(max_over_ranks(float(min(2000, max(1, round(prewarm_s / one)))), torch, dist, world))
             for i in range(n):
                 fn()
                 if i % 8 == 7:
-                    torch.cuda.synchronize()
-            torch.cuda.synchronize()
+                    drain()
+            drain()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        torch.cuda.synchronize()
+        drain()
         if world > 1:
             dist.barrier()
         return max_over_ranks((time.perf_counter() - t0) / reps * 1e3, torch, dist, world)
@@ -596,7 +603,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=20, convs=Non
         work["layers"] += count
 
         def layer():   # encodeImage + encodeFilters + conv2DSS in one device call, its randomness drawn first
-            return srv.conv2DSSFromTensors(cts, share, filters, meta, net.draw(n_out))
+            return srv.conv2DSSFromTensors(cts, share, filters, meta, net.draw(n_out), defer_verdict=True)
 
         if world == 1 and not prepared:
             ms = wall_ms(layer)
@@ -700,6 +707,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=20, convs=Non
             for f in calls:
                 f()
             torch.cuda.synchronize()
+            srv.raise_pending()   # the zero-filter verdicts of the pass's convolutions
 
         one_pass()
         one_pass()
@@ -716,6 +724,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=20, convs=Non
             for f in only_linear:
                 f()
             torch.cuda.synchronize()
+            srv.raise_pending()
         inorder_linear = (time.perf_counter() - t0) / passes * 1e3
         out[f"{prefix}_inorder_ms"] = inorder
         out[f"{prefix}_he_linear_inorder_ms"] = inorder_linear

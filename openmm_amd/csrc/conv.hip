@@ -1013,6 +1013,212 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ layers of at most 32 filters: no digit image
+// DenseNet121's 58 growth layers (128 -> 32, 3x3) and SqueezeNet's squeeze layers have one block of filters, so the
+// digit image of the rotated columns would be written once and read once: pw_expand_kernel's pass and the image's two
+// trips through memory bought nothing.  Here the product's own workgroup builds the digits of a 64-tap step in LDS
+// (the expand kernel's gather and byte transposes, into the same fragment order) while the previous step's products
+// run: one workgroup of eight waves per live 64-column tile; every wave gathers 8 of the step's 64 taps for the 64
+// columns, wave (wm, wn) multiplies filter tile wm by columns 16 wn .. + 15; two LDS buffers of column digits (32 KiB)
+// and weight digits (2 or 3 planes of 2 KiB), the loads of steps k + 1 and k + 2 in registers during the products of
+// step k.  Same digits, same i32 sums, same PwRed epilogue as pw_mfma_kernel: the same bits.
+// The launch also does what the digit launch did for a call from raw tensors: folds the weight pass's flag words and
+// evaluates the zero-filter rule (workgroup 0).
+constexpr int kPwNarrowLds = 2 * (2048 + 3 * 128) * 16;   // 76 KiB: two workgroups per compute unit
+__global__ __launch_bounds__(512, 4) void pw_narrow_kernel(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+                                                        const int *__restrict__ live, const uint4 *__restrict__ w8,
+                                                        const u32 *__restrict__ flag, u64 *__restrict__ acc, int M,
+                                                        int KC, size_t S, int logN, const DevMod *__restrict__ mods,
+                                                        const u64 *__restrict__ wl, int Mpad, int Cpad, PwLift lift,
+                                                        PwFold fold, u32 *__restrict__ zero_filter, int skip7) {
+  extern __shared__ uint4 pwn_lds[];
+  __shared__ u32 s_flag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (fold.wflag) {   // (a call from raw tensors: the weight pass left one word of flag bits per workgroup)
+    u32 bits = 0;
+    for (int i = tid; i < fold.n_wflag; i += 512) bits |= fold.wflag[i];
+    const int b0 = __syncthreads_or((int)(bits & 1u)), b1 = __syncthreads_or((int)(bits & 2u));
+    if (tid == 0) {
+      s_flag = (b0 ? 1u : 0u) | (b1 ? 2u : 0u);
+      if (blockIdx.x == 0) *fold.flag_out = s_flag;
+    }
+    if (fold.anymap && blockIdx.x == 0)   // conv2DOneFilter :573-580: some filter all zero mod t?
+      for (int m = 0; m < M; ++m) {
+        int any = 0;
+        for (int kg = tid; kg < fold.KG; kg += 512) any |= fold.anymap[(size_t)kg * fold.Mpad128 + m];
+        if (!__syncthreads_or(any) && tid == 0) *zero_filter = 1u;
+      }
+  } else if (tid == 0) {
+    s_flag = *flag;
+  }
+  __syncthreads();
+  const u32 fl = s_flag;
+  const size_t c0 = (size_t)live[blockIdx.x] * 64;   // first column of the tile: (window, c0/c1, limb, i)
+  const int N = 1 << logN;
+  const size_t cols = S * 4 * N;
+  const int pl = (int)((c0 >> logN) & 3);
+  if (fl & 1u) {
+    // Weights of 2^20 and more (rare): the lifted form on the vector ALU as in pw_general_core, but four filters per
+    // wave (8 waves x 4 = the 32 filters at most) so that this branch does not set the kernel's register count.
+    const int mbase = wave * 4;
+    if (mbase >= M) return;
+    const DevMod q = mods[pl & 1];
+    const size_t ocol = c0 + lane;
+    const int ii = (int)(ocol & (size_t)(N - 1));
+    const u64 *__restrict__ gbase = image + (((c0 >> (logN + 2)) * 4 + pl) << logN);
+    const size_t rstep = S * 4 * N;
+    const u64 *__restrict__ wg = wl ? wl + (size_t)(pl & 1) * Cpad * Mpad + mbase : nullptr;
+    u64 x0[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0};
+    for (int k = 0; k < Cpad; ++k) {
+      const PwChannel pc = chan[k];
+      const u64 v = gbase[(size_t)pc.row * rstep + ((ii - pc.e) & (N - 1))];
+      const u64 u = ii < pc.e ? (v ? q.q - v : 0) : v;   // X^N = -1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u64 wj = 0;
+        if (wg) {
+          wj = mbase + j < Mpad ? wg[(size_t)k * Mpad + j] : 0;
+        } else if (mbase + j < M && k < lift.C) {   // multiply_plain's fast lift of the weight, as pw_weights_body writes it
+          const u64 r = red_t(lift.raw[(size_t)(mbase + j) * lift.C + k], lift.t);
+          wj = r >= lift.thr ? r + (q.q - lift.t.q) : r;
+        }
+        const u64 p = u * wj;
+        x0[j] += p;
+        x1[j] += mulhi64(u, wj) + (x0[j] < p);
+      }
+      if ((k & 7) == 7) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x0[j] = reduce128_wide(x1[j], x0[j], q), x1[j] = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (mbase + j < M) acc[(size_t)(mbase + j) * cols + ocol] = x0[j];
+    return;
+  }
+  const int nA = (fl & 2u) ? 3 : 2;
+  const int nj = (skip7 >> (pl & 1)) & 1 ? 7 : 8;
+  constexpr int kStride = 2048 + 3 * 128;   // uint4 per buffer
+  // gather role: wave w takes taps 8 w .. + 7 of the step (its PwChannel entries are wave-uniform: scalar loads), lane =
+  // column, so a tap's 64 rotated coefficients are one 512-byte run (pw_expand_kernel splits a wave over four rows)
+  const int i = (int)(c0 & (size_t)(N - 1)) + lane;
+  const u64 *__restrict__ base = image + (((c0 >> (logN + 2)) * 4 + pl) << logN);
+  const size_t row_step = S * 4 * N;
+  const int n_wunits = nA * 2;   // 1-KiB units of weight digits per step, unit u = (digit u >> 1, filter tile u & 1)
+  struct Staged {   // one step's operands on their way from memory to LDS: nothing here reads a loaded value, so the
+    u64 v[8];       // loads stay in flight until store_step
+    u32 neg;        // bit k: tap k's coefficient wrapped around X^N = -1 and enters negated
+    uint4 w;
+  };
+  auto load_step = [&](int kc, Staged &st) {
+    u32 neg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const PwChannel pc = chan[kc * 64 + wave * 8 + k];
+      st.v[k] = base[(size_t)pc.row * row_step + ((i - pc.e) & (N - 1))];
+      neg |= (i < pc.e ? 1u : 0u) << k;
+    }
+    st.neg = neg;
+    const int u = wave < n_wunits ? wave : 0;   // (every wave loads, so that the value lives in registers; two more store)
+    st.w = w8[(size_t)kc * 1536 + ((u >> 1) * 8 + (u & 1)) * 64 + lane];
+  };
+  // unit (16 bytes) of digit plane j for this lane's column and this wave's tap group; the wave fills one half of it
+  u64 *const out_half = reinterpret_cast<u64 *>(pwn_lds + (lane >> 4) * 64 + (((wave >> 1) << 4) | (lane & 15))) + (wave & 1);
+  auto store_step = [&](int buf, const Staged &st) {
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 x = (st.neg >> k) & 1u ? 0 - st.v[k] : st.v[k];   // plain negative integers: no mod-q negation
+      const u64 d = (x + kDigitBias) ^ kDigitBias;
+      lo[k] = (u32)d, hi[k] = (u32)(d >> 32);
+    }
+    u64 *out = out_half + (size_t)buf * kStride * 2;
+    auto planes = [&](const u32 (&x)[8], int j0) {   // byte j of the 8 values -> 8 bytes: two 4x4 byte transposes
+      u32 o[4][2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const u32 a = __builtin_amdgcn_perm(x[4 * g + 1], x[4 * g], 0x05010400u);
+        const u32 b = __builtin_amdgcn_perm(x[4 * g + 1], x[4 * g], 0x07030602u);
+        const u32 c = __builtin_amdgcn_perm(x[4 * g + 3], x[4 * g + 2], 0x05010400u);
+        const u32 d = __builtin_amdgcn_perm(x[4 * g + 3], x[4 * g + 2], 0x07030602u);
+        o[0][g] = __builtin_amdgcn_perm(c, a, 0x05040100u);
+        o[1][g] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+        o[2][g] = __builtin_amdgcn_perm(d, b, 0x05040100u);
+        o[3][g] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j0 + j < nj) out[(size_t)(j0 + j) * 4 * 64 * 2] = make64(o[j][0], o[j][1]);
+    };
+    planes(lo, 0);
+    planes(hi, 4);
+    if (wave < n_wunits) pwn_lds[buf * kStride + 2048 + wave * 64 + lane] = st.w;
+  };
+  // product role: wave (wm, wn) owns filter tile wm and columns 16 wn .. + 15
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool has_tile = wm * 16 < M;
+  v4i sum[10];
+#pragma unroll
+  for (int d = 0; d < 10; ++d) sum[d] = v4i{1 << 28, 1 << 28, 1 << 28, 1 << 28};
+  auto products = [&](int buf) {
+    if (!has_tile) return;
+    const uint4 *ldsB = pwn_lds + buf * kStride, *ldsA = ldsB + 2048;
+    v4i b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint4 t = ldsB[(j * 4 + wn) * 64 + lane];
+      b[j] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (a < nA) {
+        const uint4 t = ldsA[(a * 2 + wm) * 64 + lane];
+        const v4i av = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < 7 || nj == 8) sum[a + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[j], sum[a + j], 0, 0, 0);
+      }
+    }
+  };
+  // Two steps of loads in flight: step k + 2 is requested before the products of step k, step k + 1 (requested an
+  // iteration earlier) is turned into digits behind them.  Staging slots alternate, so the loop runs in pairs.
+  Staged s0, s1;
+  load_step(0, s0);
+  if (KC > 1) load_step(1, s1);
+  store_step(0, s0);
+  __syncthreads();
+  for (int kc = 0; kc < KC; kc += 2) {
+    if (kc + 2 < KC) load_step(kc + 2, s0);
+    products(0);
+    if (kc + 1 < KC) store_step(1, s1);   // the other buffer: its readers finished at the last barrier
+    __syncthreads();
+    if (kc + 1 >= KC) break;
+    if (kc + 3 < KC) load_step(kc + 3, s1);
+    products(1);
+    if (kc + 2 < KC) store_step(0, s0);
+    __syncthreads();
+  }
+  if (!has_tile) return;
+  const size_t ocol = c0 + wn * 16 + (lane & 15);
+  const int mrow = wm * 16 + (lane >> 4) * 4;   // + r
+  const PwRed red(mods[pl & 1]);
+  u64 *__restrict__ out = acc + (size_t)mrow * cols + ocol;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    u32 p[10];
+#pragma unroll
+    for (int d = 0; d < 10; ++d) p[d] = (u32)sum[d][r];
+    const u64 val = red(p);
+    if (mrow + r < M) out[(size_t)r * cols] = val;
+  }
+}
+// MMH_PW_NARROW=0 keeps layers of at most 32 filters on the digit image (A/B measurements, tests of both forms)
+static bool pw_narrow_ok(const mmh_conv_plan *p) {
+  const char *e = getenv("MMH_PW_NARROW");
+  return !(e && e[0] == '0') && p->meta.n_filters <= 32;
+}
+
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 struct PwSizes {
@@ -1099,6 +1305,17 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
   if (mfma && form != 1) {
     // fast form on the matrix cores: byte digits of the rotated columns once, then the i8 products
     const int KC = z.Cpad64 / 64, n_live = (int)p->pw_live_tiles;
+    const int skip7n = ((ctx->q[0] >> 54) == 0 ? 1 : 0) | ((ctx->q[1] >> 54) == 0 ? 2 : 0);
+    if (pw_narrow_ok(p) && !nzmap && !switched) {   // one launch, no digit image (the non-front weight pass keeps the image)
+      if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
+      hipLaunchKernelGGL(pw_narrow_kernel, dim3((unsigned)n_live), dim3(512), kPwNarrowLds, s, image, p->d_pw_chan, p->d_pw_live,
+                         (const uint4 *)w8, flag, acc, z.M, KC, S, ctx->logN, ctx->d_mods, wl, z.Mpad, z.Cpad,
+                         PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr},
+                         fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0}, zero_filter, skip7n);
+      MMH_HIP(hipGetLastError());
+      if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
+      return MMH_OK;
+    }
     void *u8 = nullptr;
     if (scratch_alloc(&u8, (size_t)n_live * KC * 32768, s) != hipSuccess) {
       set_error("pointwise_product: allocation failed");
@@ -1342,7 +1559,9 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     p->pw_taps_padded = chan.size();
     // the product's two LDS buffers exceed the static 64 KiB: opt in (per device; plans are made on the context's)
     if (hipFuncSetAttribute((const void *)pw_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPwLdsBytes) !=
-        hipSuccess) {
+            hipSuccess ||
+        hipFuncSetAttribute((const void *)pw_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPwNarrowLds) !=
+            hipSuccess) {
       set_error("mmh_conv_plan_create: hipFuncSetAttribute failed");
       mmh_conv_plan_destroy(p);
       return MMH_ERR_INTERNAL;
@@ -1364,6 +1583,10 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     const bool never = pw_env && pw_env[0] == '0', always = pw_env && pw_env[0] == '1';
     p->direct_fresh = !never && (always || t_direct < t_fresh);
     p->direct_prepared = !never && (always || t_direct < t_prepared);
+    // Layers of at most 32 filters multiply in one launch that builds its digits itself (pw_narrow_kernel) and beat
+    // the transform route's eight or nine launches at every size measured (128 -> 32 3x3 at 56x56 / 28x28 / 14x14 /
+    // 7x7: 88 / 80 / 74 / 75 us against 328 / 133 / 92 / 82 us per layer call; 256 -> 32 1x1 at 27x27: 56 against 167)
+    if (!never && pw_narrow_ok(p) && pw_mfma_enabled(ctx)) p->direct_fresh = p->direct_prepared = true;
   }
   std::vector<u32> kept_idx, kept_off(p->n_spatial + 1, 0);
   std::vector<int> kept_rank(p->n_spatial * (size_t)N, -1);

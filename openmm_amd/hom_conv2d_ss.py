@@ -108,6 +108,7 @@ class HomConv2DSS:
         self.ctx = self.sk_ntt = self.pk_ntt = None
         self._plans = {}
         self._verdicts = None   # page-locked verdict words + events, made on first use
+        self._pending = []      # slots of calls made with defer_verdict, read by raise_pending()
 
     # HomConv2DSS::setUp (hom_conv2d_ss.cc:467-495): sk_ntt [L,N] (client), pk_ntt [2,L,N] (server)
     def setUp(self, ctx, sk_ntt=None, pk_ntt=None):
@@ -231,13 +232,17 @@ class HomConv2DSS:
     # encodeImage + encodeFilters + conv2DSS as CheetahLinear::conv2d chains them (cheetah-api.cpp:401-445), in one
     # device call from the raw tensors: the server's share [C, H, W] (None when the input is not shared) and the
     # filters [M, C, fh, fw]; bit-identical to the three-call form
-    def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand, inline_verdict=False, out=None):
+    def conv2DSSFromTensors(self, img_share0, share_tensor, filters, meta, rand, inline_verdict=False, out=None,
+                            defer_verdict=False):
         """out: optional (out_cts [n_out,2,1,N], out_share out_shape) buffers to write into instead of fresh ones
         (pre-sized assembly buffers of the sharded form, openmm_amd/sharding.py).
         The zero-filter rule (conv2DOneFilter :573-580) is evaluated inside the call; by default its verdict is read
         early, from page-locked memory behind the call's second launch (mmh_conv_server_tensors_ev), so the host
         raises the reference's error without waiting for the products.  inline_verdict: the older form, the verdict
-        in device memory and read when the whole call has run."""
+        in device memory and read when the whole call has run.  defer_verdict: the call returns without waiting at
+        all and the verdict is read by raise_pending() behind the caller's own synchronisation -- what the C++ host
+        does (it synchronises once per layer anyway, before the send: openmm_amd/host/cheetah_linear.cc) and what a
+        caller that enqueues many layers ahead wants; at most 256 calls may be pending."""
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
         self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
@@ -268,15 +273,26 @@ class HomConv2DSS:
         else:
             # the verdict lands in page-locked memory behind the call's second launch; wait for that point alone
             if self._verdicts is None:
-                self._verdicts = L.VerdictRing()
+                self._verdicts = L.VerdictRing(256)
+            self._need(len(self._pending) < 255, 5, "conv2DSS: too many deferred verdicts, call raise_pending()")
             slot, word, event = self._verdicts.take()
             L.check(self.ctx.lib.mmh_conv_server_tensors_ev(p.handle, L.dptr(img_share0), share_ptr, L.dptr(filters),
                                                             L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),
                                                             L.dptr(out_cts), L.dptr(out_share), word, event,
                                                             L._stream_ptr()))
+            if defer_verdict:
+                self._pending.append(slot)
+                return out_cts, out_share
             nz = self._verdicts.read(slot) == 0   # true when no filter is all zero
         self._need(nz, 8, "conv2DOneFilter: filter with all zero is not supported")
         return out_cts, out_share
+
+    def raise_pending(self):
+        """Behind a synchronisation of the stream: the zero-filter verdicts of the calls made with defer_verdict since
+        the last time; raises the reference's error if any of them saw an all-zero filter."""
+        slots, self._pending = self._pending, []
+        bad = [i for i in slots if int(self._verdicts.words[i]) != 0]
+        self._need(not bad, 8, "conv2DOneFilter: filter with all zero is not supported")
 
     # static weights: encode once per model, then conv2DSSPrepared per inference (same bits as
     # conv2DSSFromWeights); the zero-filter rule of conv2DOneFilter :573-580 is settled here

@@ -53,7 +53,7 @@ def oracle_layer(ishape, fhw, M, same, stride, shared, wbound=1 << 12):
                 ref_out=ref_out, ref_share=ref_share, fshape=fshape)
 
 
-def check_routes(monkeypatch, L, ishape, M, same, stride, shared, routes=("0", "1", "1p", "model"), prepared=True, decrypt=False):
+def check_routes(monkeypatch, L, ishape, M, same, stride, shared, routes=("0", "1", "1p", "1n", "model"), prepared=True, decrypt=False):
     import openmm_amd
     from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
     g = openmm_amd.Context(N, (60, 49), T)
@@ -67,10 +67,13 @@ def check_routes(monkeypatch, L, ishape, M, same, stride, shared, routes=("0", "
             monkeypatch.setenv("MMH_CONV_POINTWISE", route[0])     # read when the plan is made
         # the direct route's product items may own both limbs of their columns (conv.hip, PwItems::paired); the
         # library pairs a layer when it has enough items, "1p" / "1" force every layer / none (read on every call)
-        if route in ("1", "1p"):
-            monkeypatch.setenv("MMH_PW_PAIRED", "1" if route == "1p" else "0")
-        else:
-            monkeypatch.delenv("MMH_PW_PAIRED", raising=False)
+        # layers of at most 32 filters build their digits inside the product kernel by default ("1n"); "1" / "1p" keep
+        # them on the digit image
+        for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)), ("MMH_PW_NARROW", {"1": "0", "1p": "0"}.get(route))):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
         srv = HomConv2DSS()
         srv.setUp(g, pk_ntt=dev(L["pk"]))
         # the re-sharing tail has two forms picked by the number of output ciphertexts (bfv.hip): both, and the default
@@ -108,7 +111,7 @@ def test_headline_layer_full_size_bit_exact(monkeypatch):
     ishape, M = (64, 56, 56), 64
     L = oracle_layer(ishape, (3, 3), M, 1, 1, True)
     assert (L["cv"].n_in, L["cv"].n_out) == (64, 64)
-    check_routes(monkeypatch, L, ishape, M, 1, 1, True, routes=("model", "0", "1", "1p"), decrypt=True)
+    check_routes(monkeypatch, L, ishape, M, 1, 1, True, routes=("model", "0", "1", "1p", "1n"), decrypt=True)
 
 
 def test_two_filter_tiles_full_k(monkeypatch):

@@ -94,7 +94,7 @@ def test_direct_route_weight_forms(mm, monkeypatch, wbound, ishape, fhw, M, same
 
 # the server multiplies either through filter transforms or through the direct tap-wise matrix product; the
 # plan's cost model picks one ("model"), MMH_CONV_POINTWISE forces the transform ("0") or the direct route ("1")
-@pytest.mark.parametrize("route", ["model", "0", "1", "1p"])
+@pytest.mark.parametrize("route", ["model", "0", "1", "1p", "1n"])
 @pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", [((9, 20, 20), (3, 3), 5, 1, 1, True),
                                                              ((40, 14, 14), (1, 1), 70, 0, 1, True),
                                                              ((3, 33, 33), (3, 3), 4, 0, 2, False)])
@@ -107,7 +107,7 @@ def test_conv_layer_bit_exact_n8192(mm, monkeypatch, ishape, fhw, M, same, strid
     test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, shared, route)
 
 
-@pytest.mark.parametrize("route", ["0", "1", "1p"])
+@pytest.mark.parametrize("route", ["0", "1", "1p", "1n"])
 @pytest.mark.parametrize("ring_bits", [32, 41, 44])
 def test_conv_layer_bit_exact_other_rings(mm, monkeypatch, ring_bits, route):
     """the ring sizes of the other shipped networks (bitlength 32 for SqueezeNet / DenseNet121, 41 in
@@ -119,7 +119,7 @@ def test_conv_layer_bit_exact_other_rings(mm, monkeypatch, ring_bits, route):
     test_conv_layer_bit_exact(mm, monkeypatch, (40, 14, 14), (1, 1), 70, 0, 2, True, route)
 
 
-@pytest.mark.parametrize("route", ["model", "0", "1", "1p"])
+@pytest.mark.parametrize("route", ["model", "0", "1", "1p", "1n"])
 @pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", CASES)
 def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, shared, route):
     from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
@@ -127,9 +127,13 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
         monkeypatch.setenv("MMH_CONV_POINTWISE", route[0])   # read when the plan is made
     # "1p": the direct route with the product kernel's items owning both limbs and the tail fed the mod-switched
     # accumulator (the library pairs only layers with enough items by itself: none of these small cases); "1": never
-    monkeypatch.setenv("MMH_PW_PAIRED", "1" if route == "1p" else "0" if route == "1" else "")
-    if route not in ("1", "1p"):
-        monkeypatch.delenv("MMH_PW_PAIRED")
+    # "1n": layers of at most 32 filters through the kernel that builds its digits itself (the default for them);
+    # "1" and "1p" keep them on the digit image, so that the wide kernel sees these small cases too
+    for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)), ("MMH_PW_NARROW", {"1": "0", "1p": "0"}.get(route))):
+        if val is None:
+            monkeypatch.delenv(var, raising=False)
+        else:
+            monkeypatch.setenv(var, val)
     o, g = OracleCtx(N, (60, 49), T), mm.Context(N, (60, 49), T)
     fshape = (ishape[0],) + tuple(fhw)
     cv = ConvOracle(o, ishape, fshape, M, same, stride, shared)
@@ -173,7 +177,7 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
     assert np.array_equal(host(one_out), ref_out)
     # ... and so does the form that also takes the server's share as the raw tensor (CheetahLinear::conv2d in one call)
     t_out, t_share = server.conv2DSSFromTensors(got_cts, dev(share1) if shared else None, dev(filters), meta,
-                                                (dev(u), dev(e1), dev(mask)), inline_verdict=route in ("1", "1p"))
+                                                (dev(u), dev(e1), dev(mask)), inline_verdict=route in ("1", "1p", "1n"))
     assert np.array_equal(host(t_out), ref_out) and np.array_equal(host(t_share), ref_share)
     assert np.array_equal(host(one_share), ref_share)
     # ... and so does the call on filters prepared once (static weights)

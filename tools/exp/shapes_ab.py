@@ -26,6 +26,7 @@ def timed(call, value):
     for _ in range(3):
         call()
     torch.cuda.synchronize()
+    net.srv.raise_pending()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 0
     import time
@@ -33,12 +34,17 @@ def timed(call, value):
     while time.perf_counter() < t_end:   # settle the clocks
         call()
         n += 1
+        if n % 64 == 0:
+            torch.cuda.synchronize()
+            net.srv.raise_pending()
     torch.cuda.synchronize()
+    net.srv.raise_pending()
     e0.record()
     for _ in range(reps):
         call()
     e1.record()
     torch.cuda.synchronize()
+    net.srv.raise_pending()
     return e0.elapsed_time(e1) / reps * 1e3
 
 

@@ -19,4 +19,5 @@ for p in range(passes + 1):
     for f in calls:
         f()
     torch.cuda.synchronize()
+    net.srv.raise_pending()
     print(f"pass {p}: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
