@@ -503,20 +503,18 @@ class NetworkLegs:
 
         def call():
             s = L._stream_ptr()
-            # Ring2Field, ALICE = COT sender (truncation.cpp:518-581; silent_ot.h:129-163)
-            L.check(lib.mmh_r2f_pre(1, L.dptr(x), n, l, p, L.dptr(tmp), L.dptr(msb), L.dptr(corr), s))
-            L.check(lib.mmh_cot_send(L.dptr(rcm[0]), delta, seed, self.gid, L.dptr(corr), n, l, p, 1, L.dptr(y),
-                                     L.dptr(wires[0]), s))
+            # Ring2Field, ALICE = COT sender (truncation.cpp:518-581; silent_ot.h:129-163): pre step, the sender's
+            # post-processing and the post step feeding encodeVector in one launch + BatchEncoder's transform
+            in_pts = torch.empty(n_ct, N, dtype=torch.int64, device="cuda")
+            L.check(lib.mmh_cot_send_r2f_encode(self.bn.ctx.handle, L.dptr(rcm[0]), delta, seed, self.gid, L.dptr(x), n, l,
+                                                L.dptr(in_pts), L.dptr(wires[0]), s))
             self.gid += gids.value
-            in_pts = self.bn.encodeVectorFromRing(1, (tmp, msb, y), l, meta)     # post step fused into encodeVector
             sc_pts = self.bn.encodeScales(scale, meta)
             out_cts, share = self.bn.bn(cts, in_pts, sc_pts, meta, self.sampler.words(n))   # r drawn here
-            # Field2Ring_with_Truncate on her share (truncation.cpp:639-695; silent_ot.h:85-127)
-            L.check(lib.mmh_f2r_pre(1, L.dptr(share), n, p, K_SCALE, L.dptr(tmp), L.dptr(msb), L.dptr(corr), s))
-            L.check(lib.mmh_cot_send(L.dptr(rcm[1]), delta, seed, self.gid, L.dptr(corr), n, l, p, 0, L.dptr(y),
-                                     L.dptr(wires[1]), s))
+            # Field2Ring_with_Truncate on her share (truncation.cpp:639-695; silent_ot.h:85-127), one launch
+            L.check(lib.mmh_cot_send_f2r(L.dptr(rcm[1]), delta, seed, self.gid, L.dptr(share), n, p, l, K_SCALE,
+                                         L.dptr(out), L.dptr(wires[1]), s))
             self.gid += gids.value
-            L.check(lib.mmh_f2r_trunc_post(1, L.dptr(tmp), L.dptr(msb), L.dptr(y), n, p, l, K_SCALE, L.dptr(out), s))
             return out_cts, out
         return call
 

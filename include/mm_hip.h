@@ -647,6 +647,21 @@ int mmh_cot_send(const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t 
                  uint8_t *d_wire, void *stream);
 int mmh_cot_recv(const uint64_t *d_rcm, const uint8_t *d_choice, const uint64_t seed[2], uint64_t gid0,
                  const uint8_t *d_wire, size_t n, int l, uint64_t p, int prime, uint64_t *d_data, void *stream);
+/* A conversion of the COT sender's (ALICE of the Truncation object) in ONE launch: the pre step, the sender's
+ * post-processing and the post step fused, so tmp / msb / corr / data0 never exist in memory.  Same outputs and the
+ * same wire bytes as the calls they replace (ElemWiseActModelVectorMult runs both around CheetahLinear::bn,
+ * library_fixed_uniform_cheetah.cpp:567-600):
+ *   mmh_cot_send_f2r         Truncation::field_to_ring (shift < 0, truncation.cpp:583-637) / field_to_ring_with_truncate
+ *                            (shift >= 0, :639-695) = mmh_f2r_pre + mmh_cot_send(prime = 0, l = bw) + mmh_f2r[_trunc]_post;
+ *   mmh_cot_send_r2f_encode  Truncation::ring_to_field (:518-581) feeding HomBNSS::encodeVector (hom_bn_ss.cc:203-233)
+ *                            = mmh_r2f_pre + mmh_cot_send(prime = 1, p = ctx's t) + mmh_bn_encode_vector_r2f: d_pts are the
+ *                            plaintexts CheetahLinear::bn adds to the client's ciphertexts. */
+int mmh_cot_send_f2r(const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t seed[2], uint64_t gid0,
+                     const uint64_t *d_share, size_t n, uint64_t p, int bw, int shift, uint64_t *d_out, uint8_t *d_wire,
+                     void *stream);
+int mmh_cot_send_r2f_encode(const mmh_ctx *ctx, const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t seed[2],
+                            uint64_t gid0, const uint64_t *d_x, size_t n, int bw, uint64_t *d_pts, uint8_t *d_wire,
+                            void *stream);
 
 #ifdef __cplusplus
 }

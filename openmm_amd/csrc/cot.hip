@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "convert_device.hpp"
 
 namespace mmh {
 namespace {
@@ -145,14 +146,31 @@ __device__ __forceinline__ u64 mod128(u64 hi, u64 lo, const PrimeMod &m) {
 
 __device__ __forceinline__ u64 words64(u32 lo, u32 hi) { return make64(lo, hi); }
 
+// A modulus conversion of ALICE's (the COT sender's, truncation.cpp:518-695) run INSIDE the sender's launch: the pre
+// step makes the correlation from the share instead of reading it, the post step takes data0 as it is computed, so
+// the conversion is one launch instead of three and tmp / msb / corr / data0 never exist in memory.
+//   CONV_R2F_ENCODE  ring_to_field (:518-581) whose field elements go straight into BatchEncoder's slot order for
+//                    HomBNSS::encodeVector (hom_bn_ss.cc:203-233; the inverse transform follows): out = pts [n_ct][N]
+//   CONV_F2R         field_to_ring (:583-637) or, truncating, field_to_ring_with_truncate (:639-695): out = [n]
+enum { CONV_NONE = 0, CONV_R2F_ENCODE = 1, CONV_F2R = 2 };
+struct CotConv {
+  const u64 *in;
+  u64 *out;
+  u64 p, cv, big_mod_p;      // r2f: cv = (2^bw - 1) % p + 1, big = 2^(bw-2) % p; f2r: cv = p or p >> shift
+  int bw, shift, truncating;
+  const u32 *map;            // encode: BatchEncoder's slot map, elements per ciphertext, log2 N, Barrett constants of t = p
+  size_t sub_len;
+  int logN;
+  ModC t;
+};
 // Sender.  rcm [n] blocks; element j is hashed under key S ^ (gid0 + j in the high half).
 // Ring: wire holds, per group of 8 elements, ceil(8*l/64) words (a ragged last group ceil(rem*l/64)).
 // Prime: wire holds `bytes` bytes per element, back to back.
-template <bool PRIME>
+template <bool PRIME, int CONV = CONV_NONE>
 __global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__restrict__ rcm, uint4 delta, uint4 S,
                                                                 u64 gid0, const u64 *__restrict__ corr, size_t n,
                                                                 int l, PrimeMod pm, u64 *__restrict__ data0,
-                                                                uint8_t *__restrict__ wire) {
+                                                                uint8_t *__restrict__ wire, CotConv cv = CotConv{}) {
   __shared__ u32 table[256 * kCopies];
   __shared__ u64 stage[kCotThreads];
   fill_table(table);
@@ -170,18 +188,41 @@ __global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__re
       u32 key[4] = {S.x, S.y, S.z ^ lo32(gid), S.w ^ hi32(gid)};
       u32 blk[2][4] = {{r.x, r.y, r.z, r.w}, {r.x ^ delta.x, r.y ^ delta.y, r.z ^ delta.z, r.w ^ delta.w}};
       aes.hash<2>(key, blk);
-      const u64 c = corr[j];
+      u64 c, tmpv = 0;
+      bool m = false;
+      if (CONV == CONV_R2F_ENCODE) {   // truncation.cpp:525-531, :561-564, :546-548 (ALICE)
+        tmpv = (cv.in[j] + (u64(1) << (cv.bw - 2))) & bw_mask(cv.bw);
+        m = (tmpv >> (cv.bw - 1)) & 1;
+        c = m ? 0 : cv.cv;
+      } else if (CONV == CONV_F2R) {   // :601-607 / :657-665 (ALICE)
+        tmpv = f2r_pre_elem(kAlice, cv.in[j], cv.p, m);
+        c = m ? 0 : cv.cv;
+      } else {
+        c = corr[j];
+      }
       if (PRIME) {  // silent_ot.h:153-156
         const u64 t0 = mod128(words64(blk[0][2], blk[0][3]), words64(blk[0][0], blk[0][1]), pm);
         const u64 t1 = mod128(words64(blk[1][2], blk[1][3]), words64(blk[1][0], blk[1][1]), pm);
-        data0[j] = t0;
+        if (CONV == CONV_R2F_ENCODE) {   // :551-554, :571, then the chunking and slot scatter of encodeVector
+          const u64 f = r2f_post_elem(kAlice, tmpv, m, t0, cv.p, cv.cv, cv.big_mod_p);
+          const size_t k = j / cv.sub_len, i = j - k * cv.sub_len;
+          cv.out[(k << cv.logN) + cv.map[i]] = barrett128(0, f, cv.t.q, cv.t.barrett_hi, cv.t.barrett_lo);
+        } else {
+          data0[j] = t0;
+        }
         // (t0 + t1 + corr) % p over 128 bits: corr is any 64-bit value
         const u64 s = t0 + t1, lo = s + c;
         const u64 hi = (u64)(s < t0) + (u64)(lo < s);
         cd = mod128(hi, lo, pm);
       } else {  // silent_ot.h:112-115
         const u64 d0 = words64(blk[0][0], blk[0][1]) & mask;
-        data0[j] = d0;
+        if (CONV == CONV_F2R) {   // truncation.cpp:609-611, :626-634 / :667-669, :684-692 (ALICE); mask = 2^bw - 1 = 2^l - 1
+          const u64 yy = m ? ((cv.cv - d0) & mask) : ((0 - d0) & mask), big = cv.p / 4;
+          const u64 o = cv.truncating ? ((tmpv - big) >> cv.shift) - yy : tmpv - yy - big;
+          cv.out[j] = o & mask;
+        } else {
+          data0[j] = d0;
+        }
         cd = (c + d0 + words64(blk[1][0], blk[1][1])) & mask;
       }
     }
@@ -297,6 +338,22 @@ unsigned cot_grid(size_t n) {
 }
 uint4 as_block(const uint64_t v[2]) { return uint4{(u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32)}; }
 }  // namespace
+// ALICE's ring_to_field through the sender's launch, field elements scattered into BatchEncoder's slot order (used by
+// mmh_cot_send_r2f_encode, fc_bn.hip, which runs the inverse transform behind it).  pts must hold zeros where no
+// element lands (a ragged last ciphertext): the caller clears those.
+int cot_send_r2f_encode_launch(const u64 *d_rcm, const uint64_t delta[2], const uint64_t seed[2], u64 gid0, const u64 *d_x,
+                               size_t n, int bw, u64 p, u64 *d_pts, const u32 *d_map, size_t sub_len, int logN,
+                               const ModC &t, uint8_t *d_wire, hipStream_t s) {
+  const u64 mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
+  CotConv cv{};
+  cv.in = d_x, cv.out = d_pts, cv.p = p, cv.cv = mask % p + 1, cv.big_mod_p = (u64(1) << (bw - 2)) % p, cv.bw = bw;
+  cv.map = d_map, cv.sub_len = sub_len, cv.logN = logN, cv.t = t;
+  hipLaunchKernelGGL((cot_send_kernel<true, CONV_R2F_ENCODE>), dim3(cot_grid(n)), dim3(kCotThreads), 0, s,
+                     (const uint4 *)d_rcm, as_block(delta), as_block(seed), gid0, (const u64 *)nullptr, n, 64, make_prime(p),
+                     (u64 *)nullptr, d_wire, cv);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
 }  // namespace mmh
 
 using namespace mmh;
@@ -363,6 +420,26 @@ extern "C" int mmh_cot_recv(const uint64_t *d_rcm, const uint8_t *d_choice, cons
   else
     hipLaunchKernelGGL(cot_recv_kernel<false>, grid, block, 0, (hipStream_t)stream, (const uint4 *)d_rcm, d_choice,
                        as_block(seed), gid0, d_wire, n, l, pm, d_data);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+
+// ALICE's field_to_ring (shift < 0) / field_to_ring_with_truncate (shift >= 0) as the COT sender in ONE launch:
+// mmh_f2r_pre, mmh_cot_send (mod 2^bw) and mmh_f2r_post / mmh_f2r_trunc_post give the same d_out and the same wire.
+extern "C" int mmh_cot_send_f2r(const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t seed[2], uint64_t gid0,
+                                const uint64_t *d_share, size_t n, uint64_t p, int bw, int shift, uint64_t *d_out,
+                                uint8_t *d_wire, void *stream) {
+  MMH_REQUIRE(delta && seed, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(n == 0 || (d_rcm && d_share && d_out && d_wire), MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 1 && bw <= 64 && p >= 4 && shift < 64, MMH_ERR_INVALID_ARG);
+  if (int rc = cot_check(n, bw, p, 0)) return rc;
+  if (n == 0) return MMH_OK;
+  CotConv cv{};
+  cv.in = d_share, cv.out = d_out, cv.p = p, cv.truncating = shift >= 0, cv.shift = shift >= 0 ? shift : 0;
+  cv.cv = shift >= 0 ? p >> shift : p, cv.bw = bw;
+  hipLaunchKernelGGL((cot_send_kernel<false, CONV_F2R>), dim3(cot_grid(n)), dim3(kCotThreads), 0, (hipStream_t)stream,
+                     (const uint4 *)d_rcm, as_block(delta), as_block(seed), gid0, (const uint64_t *)nullptr, n, bw,
+                     make_prime(2), (uint64_t *)nullptr, d_wire, cv);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }

@@ -14,6 +14,9 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
 int ntt_dispatch(const mmh_ctx *ctx, bool inverse, u64 *d_polys, size_t n_polys, int limbs, int mod_base, hipStream_t s);
 int ntt_inv_product_each_dispatch(const mmh_ctx *ctx, const u64 *d_pt_ntt, const u64 *d_ct_ntt, const u64 *d_pt2_ntt,
                                   const u64 *d_ct2_ntt, u64 *d_out, size_t n, int limbs, hipStream_t s);
+int cot_send_r2f_encode_launch(const u64 *d_rcm, const uint64_t delta[2], const uint64_t seed[2], u64 gid0, const u64 *d_x,
+                               size_t n, int bw, u64 p, u64 *d_pts, const u32 *d_map, size_t sub_len, int logN,
+                               const ModC &t, uint8_t *d_wire, hipStream_t s);
 int launch_share_from_mask(const mmh_ctx *ctx, const u64 *r, u64 *out, size_t groups, size_t n_targets,
                            size_t n_spatial, size_t plane, const u32 *coef, const u32 *dst, const u32 *slice,
                            hipStream_t s);
@@ -567,6 +570,26 @@ extern "C" int mmh_bn_encode_vector_r2f(const mmh_ctx *ctx, int party, const uin
   hipLaunchKernelGGL(r2f_post_scatter_kernel, dim3(nblk(n_ct << ctx->logN)), dim3(256), 0, s, party, d_tmp, d_msb, d_y,
                      d_pts, n_ct, n, sub, ctx->logN, ctx->d_slot_map, ctx->bfv.t, mask % p + 1, (u64(1) << (bw - 2)) % p);
   MMH_HIP(hipGetLastError());
+  return ntt_dispatch(ctx, true, d_pts, n_ct, 1, (int)ctx->L, s);   // BatchEncoder::encode's inverse transform mod t
+}
+// ALICE's Ring2Field in front of CheetahLinear::bn as the COT sender (library_fixed_uniform_cheetah.cpp:567-600,
+// truncation.cpp:518-581, silent_ot.h:129-163), through to the plaintexts bn adds to the client's ciphertexts: mmh_r2f_pre,
+// mmh_cot_send (mod p) and mmh_bn_encode_vector_r2f in one launch plus BatchEncoder's inverse transform; same d_pts and
+// the same wire bytes as the three calls.
+extern "C" int mmh_cot_send_r2f_encode(const mmh_ctx *ctx, const uint64_t *d_rcm, const uint64_t delta[2],
+                                       const uint64_t seed[2], uint64_t gid0, const uint64_t *d_x, size_t n, int bw,
+                                       uint64_t *d_pts, uint8_t *d_wire, void *stream) {
+  MMH_DEVICE_SCOPE(ctx);
+  size_t sub, n_ct;
+  CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
+  MMH_REQUIRE(d_rcm && delta && seed && d_x && d_pts && d_wire, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 2 && bw <= 64 && n <= ((size_t)1 << 40), MMH_ERR_INVALID_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = ctx->N;
+  if (n != n_ct * N)   // the slots past the last element of a short last ciphertext hold zeros
+    MMH_HIP(hipMemsetAsync(d_pts + (n_ct - 1) * N, 0, N * 8, s));
+  CHECK_RC(cot_send_r2f_encode_launch(d_rcm, delta, seed, gid0, d_x, n, bw, ctx->t, d_pts, ctx->d_slot_map, sub, ctx->logN,
+                                      ctx->bfv.t, d_wire, s));
   return ntt_dispatch(ctx, true, d_pts, n_ct, 1, (int)ctx->L, s);   // BatchEncoder::encode's inverse transform mod t
 }
 extern "C" int mmh_bn_encrypt_vector_r2f(const mmh_ctx *ctx, const uint64_t *d_sk_ntt, int party, const uint64_t *d_tmp,

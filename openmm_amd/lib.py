@@ -162,6 +162,8 @@ SIGNATURES = {
     "mmh_cot_wire_bytes": [_sz, _int, _u64, _int, C.POINTER(_sz)],
     "mmh_cot_gids": [_sz, C.POINTER(_u64)],
     "mmh_cot_send": [_vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _int, _u64, _int, _vp, _vp, _vp],
+    "mmh_cot_send_f2r": [_vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _u64, _int, _int, _vp, _vp, _vp],
+    "mmh_cot_send_r2f_encode": [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _int, _vp, _vp, _vp],
     "mmh_cot_recv": [_vp, _vp, C.POINTER(_u64), _u64, _vp, _sz, _int, _u64, _int, _vp, _vp],
 }
 

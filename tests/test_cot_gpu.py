@@ -159,3 +159,66 @@ def test_cot_shards_are_independent(mm, l, p):
         got_wire.append(d_wire.cpu().numpy().view(np.uint8)[:nb.value])
     assert np.array_equal(np.concatenate(got_data0), data0)
     assert np.array_equal(np.concatenate(got_wire), wire)
+
+
+@pytest.mark.parametrize("n", [1, 9, 1003, 4096, 3 * 4096 + 77])
+def test_sender_conversions_fused_with_the_cot(mm, n):
+    """ALICE's Ring2Field -> encodeVector and Field2Ring[_with_Truncate] as the COT sender, each in one launch
+    (mmh_cot_send_r2f_encode, mmh_cot_send_f2r): the outputs and every byte of the wire against the ORACLE's separate
+    steps (pre step, sender's post-processing, post step, HomBNSS::encodeVector) on the same blocks."""
+    import torch
+    from openmm_amd.lib import check, dptr, load_library
+    from tests.oracle_binding import OracleCtx
+    from tests.oracle_layers import BnOracle
+    o, lib = load(), load_library()
+    N, bw, p, gid0 = 4096, 37, PRIMES[37], 8 * 1234
+    delta = splitmix64(SEED + 70, 2) | np.uint64(1)
+    S, rcm = splitmix64(SEED + 71, 2), splitmix64(SEED + 72, 2 * n)
+    d_rcm = dev(rcm)
+
+    def oracle_send(corr, l, prime):
+        nbytes = o.mmo_cot_wire_bytes(n, l, p, prime)
+        wire, data0 = np.zeros(nbytes + 8, np.uint8), np.zeros(n, np.uint64)
+        o.mmo_cot_send(A(rcm), A(delta), A(S), gid0, A(corr), n, l, p, prime, A(data0), A(wire))
+        return data0, wire[:nbytes]
+
+    def gpu_wire(nbytes):
+        return torch.full(((nbytes + 7) // 8 + 1,), -1, dtype=torch.int64, device="cuda")
+
+    # ring -> field, then BatchEncoder's plaintexts
+    x = splitmix64(SEED + 73, n) & np.uint64((1 << bw) - 1)
+    x[:min(3, n)] = [0, (1 << bw) - 1, 1 << (bw - 1)][:min(3, n)]
+    tmp, msb, corr, fld = np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    o.mmo_r2f_pre(1, A(x), n, bw, p, A(tmp), A(msb), A(corr))
+    y, wire = oracle_send(corr, 0, 1)
+    o.mmo_r2f_post(1, A(tmp), A(msb), A(y), n, bw, p, A(fld))
+    ref_pts = BnOracle(OracleCtx(N, (60, 49), p), n).encode(fld)
+    g = mm.Context(N, (60, 49), p)
+    d_pts = torch.full(ref_pts.shape, -1, dtype=torch.int64, device="cuda")
+    d_wire = gpu_wire(len(wire))
+    check(lib.mmh_cot_send_r2f_encode(g.handle, dptr(d_rcm), u2(delta), u2(S), gid0, dptr(dev(x)), n, bw, dptr(d_pts),
+                                      dptr(d_wire), None))
+    assert np.array_equal(host(d_pts), ref_pts)
+    gw = d_wire.cpu().numpy().view(np.uint8)
+    assert np.array_equal(gw[:len(wire)], wire) and (gw[len(wire):] == 0xFF).all()
+    # field -> ring, plain and truncating
+    share = splitmix64(SEED + 74, n) % np.uint64(p)
+    share[:min(3, n)] = [0, p - 1, p // 2 + 1][:min(3, n)]
+    for shift in (-1, 0, 12):
+        o.mmo_f2r_pre(1, A(share), n, p, max(shift, 0), A(tmp), A(msb), A(corr))
+        y, wire = oracle_send(corr, bw, 0)
+        ref = np.zeros(n, np.uint64)
+        if shift < 0:
+            o.mmo_f2r_post(1, A(tmp), A(msb), A(y), n, p, bw, A(ref))
+        else:
+            o.mmo_f2r_trunc_post(1, A(tmp), A(msb), A(y), n, p, bw, shift, A(ref))
+        d_out = torch.empty(n, dtype=torch.int64, device="cuda")
+        d_wire = gpu_wire(len(wire))
+        check(lib.mmh_cot_send_f2r(dptr(d_rcm), u2(delta), u2(S), gid0, dptr(dev(share)), n, p, bw, shift, dptr(d_out),
+                                   dptr(d_wire), None))
+        assert np.array_equal(host(d_out), ref), f"shift {shift}"
+        gw = d_wire.cpu().numpy().view(np.uint8)
+        assert np.array_equal(gw[:len(wire)], wire) and (gw[len(wire):] == 0xFF).all()
+    with pytest.raises(mm.MMHError):
+        check(lib.mmh_cot_send_f2r(dptr(d_rcm), u2(delta), u2(S), gid0, dptr(dev(share)), n, p, 0, 0, dptr(d_out),
+                                   dptr(d_wire), None))
