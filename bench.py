@@ -466,7 +466,8 @@ class NetworkLegs:
         # (the zero-filter verdict of conv2DOneFilter is computed inside the call and read by srv.raise_pending() behind
         # the caller's synchronisation, as the C++ host reads it behind the one it needs before the send: the host does
         # not stop at every layer)
-        return lambda: self.srv.conv2DSSFromTensors(cts, share, filters, meta, self.draw(plan.n_out), defer_verdict=True)
+        # randomness: the call draws u, e1 and the mask itself (mmh_conv_server_tensors_sampled), as conv2DSS does
+        return lambda: self.srv.conv2DSSFromTensors(cts, share, filters, meta, self.sampler, defer_verdict=True)
 
     def fc_call(self, rows, cols):
         from openmm_amd.hom_fc_ss import Meta as FcMeta
@@ -601,7 +602,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=20, convs=Non
         work["layers"] += count
 
         def layer():   # encodeImage + encodeFilters + conv2DSS in one device call, its randomness drawn first
-            return srv.conv2DSSFromTensors(cts, share, filters, meta, net.draw(n_out), defer_verdict=True)
+            return srv.conv2DSSFromTensors(cts, share, filters, meta, net.sampler, defer_verdict=True)
 
         if world == 1 and not prepared:
             ms = wall_ms(layer)

@@ -366,6 +366,16 @@ int mmh_conv_server_tensors_ev(const mmh_conv_plan *plan, const uint64_t *d_in_c
                                const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const int64_t *d_u,
                                const int64_t *d_e1, const uint64_t *d_mask, uint64_t *d_out_cts,
                                uint64_t *d_out_share, uint32_t *zero_filter, void *verdict_event, void *stream);
+/* mmh_conv_server_tensors_ev that DRAWS the re-sharing's randomness itself, as conv2DSS does inside the call
+ * (sample_poly_ternary :302, SEAL_NOISE_SAMPLER :329, sample_poly_uniform :206): u, e1 and the mask are polynomials
+ * [first_poly, first_poly + n_out) of the three streams mmh_sample_reshare(ctx, key, stream_id, ...) draws, so the call
+ * equals mmh_sample_reshare_range + mmh_conv_server_tensors_ev bit for bit -- without the sampling launch and without
+ * u in memory: on the direct route the call's front launch draws u where it transforms it and e1 / the mask beside
+ * its other work, and for a layer of few output ciphertexts it finishes the pk-encryption of zero there as well. */
+int mmh_conv_server_tensors_sampled(const mmh_conv_plan *plan, const uint64_t *d_in_cts, const uint64_t *d_share,
+                                    const uint64_t *d_filters, const uint64_t *d_pk_ntt_last, const uint32_t key[8],
+                                    uint64_t stream_id, size_t first_poly, uint64_t *d_out_cts, uint64_t *d_out_share,
+                                    uint32_t *zero_filter, void *verdict_event, void *stream);
 /* The conv2DOneFilter :573-580 rule on the raw filters [M][C][fh][fw]: *d_flag (device word) becomes 1
  * when some filter is all zero mod t, else 0.  Asynchronous, so a caller can read the verdict back after
  * it has enqueued the layer. */

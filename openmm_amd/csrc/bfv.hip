@@ -686,6 +686,10 @@ int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
   return reshare_tail_approx_u(ctx, d_acc, acc_ntt_form, n, d_pk_ntt_last, d_u, nullptr, d_e1, d_mask, d_keep,
                                keep_period, d_out, s, d_share_dst, share_plane, d_share_out);
 }
+size_t reshare_split_max() {
+  const char *split_env = getenv("MMH_TAIL_SPLIT_MAX");
+  return split_env ? (size_t)atol(split_env) : (size_t)128;
+}
 // d_u_ntt: u already transformed (the front launch of a direct-route layer does it beside its own work), else null
 // acc_switched: d_acc holds the accumulator AFTER divide_and_round_q_last, [n][2][N] canonical mod q0 in coefficient
 // form (the matrix-core product's paired items write it so), instead of [n][2][2][N] at the first level
@@ -709,9 +713,7 @@ int reshare_tail_approx_u(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, siz
   // out and the tail runs one thread per coefficient instead; same bits.  Measured per layer call (GPU time, fused
   // against split): 64 ciphertexts 66.7 / 59.8 us, 256: 83.5 / 87.3, 512: 111.9 / 128.9, 1024: 203 / 243.
   // MMH_TAIL_SPLIT_MAX overrides the size (A/B measurements, tests of both forms).
-  const char *split_env = getenv("MMH_TAIL_SPLIT_MAX");
-  const size_t split_max = split_env ? (size_t)atol(split_env) : (size_t)128;
-  if (n <= split_max) {
+  if (n <= reshare_split_max()) {
     StreamBuf z(s);
     MMH_HIP(z.alloc(n * 2 * N * 8));
     CHECK_RC(ntt_inv_product_dispatch(ctx, d_u_ntt, d_pk_ntt_last, z.as<u64>(), n, 1, s));

@@ -28,6 +28,7 @@ int reshare_tail_online(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_
                         const int64_t *d_e1, const u64 *d_mask, const uint8_t *d_keep, size_t keep_period, u64 *d_out,
                         hipStream_t s, const int *d_share_dst, size_t share_plane, u64 *d_share_out,
                         bool acc_switched = false);
+size_t reshare_split_max();   // output ciphertexts up to which the tail takes its split form (bfv.hip)
 int ntt_filter_dispatch(const mmh_ctx *ctx, const u64 *d_filters, u64 *d_out, size_t n_filters, int C, int fh,
                         int fw, int wc, int n_cslices, long origin, long plane, long row, int limbs,
                         hipStream_t s);
@@ -334,15 +335,44 @@ __global__ __launch_bounds__(256) void pw_weights_kernel(PwWeightArgs a, u32 *__
 // Workgroups [0, n_u) beside them transform the ternary u of the re-sharing tail (encrypt_zero's first step,
 // hom_conv2d_ss.cc:302-306), which depends on nothing else in the call: for the small layers of a network its launch
 // was a tenth of the call.
+// A call that draws its own randomness (mmh_conv_server_tensors_sampled) has no sampling launch in front of this one:
+// the u workgroups draw the ternary polynomial they transform (SRC_TERNARY), and two more ranges of workgroups behind
+// the weights draw e1 and the mask for the tail, each from the stream and tile mmh_sample_reshare would use.  Where the
+// tail takes its split form (few output ciphertexts), the u workgroups -- two per ciphertext then -- go on to the
+// product with pk_j and the inverse transform (ntt_zero_unit12), so the tail's own transform launch falls away too.
+struct FrontDraw {
+  int mode;              // 0: u from memory; 1: u drawn in place -> u_ntt; 2: drawn, -> the encryption of zero [n][2][N]
+  const u64 *pk;         // mode 2: pk at the last level [2][N], NTT form
+  u64 *zero;
+  int64_t *e1;           // modes 1, 2: e1 and the mask [n][N], drawn by the last n_e + n_m workgroups
+  u64 *mask;
+  unsigned n_e, n_m, lo_e, lo_m;   // tiles of the noise / uniform streams that meet [first, first + total)
+  size_t first, total;
+};
 template <int LOGN>
 __global__ __launch_bounds__(256) void conv_front_kernel(ImageShareArgs ia, BfvConsts b, const DevMod *__restrict__ mods,
                                                          unsigned n_u, unsigned n_img, PwWeightArgs wa,
                                                          u32 *__restrict__ wflag, uint8_t *__restrict__ anymap,
                                                          u32 *__restrict__ zero_filter, u64 *__restrict__ u_ntt,
-                                                         NttSource usrc, const ulonglong2 *__restrict__ tables) {
+                                                         NttSource usrc, const ulonglong2 *__restrict__ tables,
+                                                         unsigned n_w, FrontDraw dr) {
   extern __shared__ __align__(16) u64 front_lds[];
   if (blockIdx.x < n_u) {
-    ntt_fwd_unit<LOGN, true, SRC_SIGNED>(blockIdx.x, u_ntt, mods, tables, 1, 0, usrc, front_lds);
+    if (dr.mode == 2) {
+      if (LOGN == 12)
+        ntt_zero_unit12<true>(blockIdx.x >> 1, mods[0], tables, usrc, dr.pk + ((size_t)(blockIdx.x & 1) << LOGN),
+                              dr.zero + ((size_t)blockIdx.x << LOGN), front_lds);
+    } else if (dr.mode == 1) {
+      ntt_fwd_unit<LOGN, true, SRC_TERNARY>(blockIdx.x, u_ntt, mods, tables, 1, 0, usrc, front_lds);
+    } else {
+      ntt_fwd_unit<LOGN, true, SRC_SIGNED>(blockIdx.x, u_ntt, mods, tables, 1, 0, usrc, front_lds);
+    }
+    return;
+  }
+  if (blockIdx.x >= n_u + n_img + n_w) {   // the tail's e1 and mask (streams sid + 1, sid + 2 of the draw)
+    const unsigned d = blockIdx.x - n_u - n_img - n_w;
+    if (d < dr.n_e) noise_block(usrc.key, usrc.sid + 1, 0, dr.lo_e + d, threadIdx.x, dr.e1, dr.total, dr.first);
+    else uniform_block(usrc.key, usrc.sid + 2, 0, dr.lo_m + (d - dr.n_e), threadIdx.x, dr.mask, dr.total, LOGN, 1, mods, dr.first);
     return;
   }
   if (blockIdx.x < n_u + n_img) {
@@ -530,6 +560,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const u64 *__restrict__ im
 // column % 16][k % 16]: the 16 bytes of a lane are the B operand of one instruction, a 64-channel step of one
 // tile is 32 KiB contiguous.  The byte order inside a lane only has to agree between the two operands.
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr u64 kDigitBias = 0x0080808080808080ull;
 
 struct PwFold {   // what conv_front_kernel left for this launch to fold (all null on the other paths)
@@ -1025,7 +1056,7 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
 // The launch also does what the digit launch did for a call from raw tensors: folds the weight pass's flag words and
 // evaluates the zero-filter rule (workgroup 0).
 constexpr int kPwNarrowLds = 2 * (2048 + 3 * 128) * 16;   // 76 KiB: two workgroups per compute unit
-__global__ __launch_bounds__(512, 4) void pw_narrow_kernel(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
+__global__ __launch_bounds__(512, 2) void pw_narrow_kernel(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
                                                         const int *__restrict__ live, const uint4 *__restrict__ w8,
                                                         const u32 *__restrict__ flag, u64 *__restrict__ acc, int M,
                                                         int KC, size_t S, int logN, const DevMod *__restrict__ mods,
@@ -1109,19 +1140,46 @@ __global__ __launch_bounds__(512, 4) void pw_narrow_kernel(const u64 *__restrict
   struct Staged {   // one step's operands on their way from memory to LDS: nothing here reads a loaded value, so the
     u64 v[8];       // loads stay in flight until store_step
     u32 neg;        // bit k: tap k's coefficient wrapped around X^N = -1 and enters negated
-    uint4 w;
+    v4u w;          // (a native vector: an asm operand)
   };
-  auto load_step = [&](int kc, Staged &st) {
+  // The loads are issued from inline asm and counted by hand (kLoadsPerStep per lane and step, in order): hipcc's own
+  // wait insertion loses track of them across the loop's back edge and drains every outstanding load before each
+  // store_step, which leaves one step of lead instead of two (1.65 us per step measured, the latency of a round trip).
+  constexpr int kLoadsPerStep = 9;
+  // (the step's eight PwChannel entries are fetched a step ahead of the loads that need them -- scalar loads, whose
+  // round trip would otherwise sit in front of every step's products)
+  struct Taps {
+    PwChannel pc[8];
+  };
+  auto fetch_taps = [&](int kc, Taps &tp) {
+    if (kc >= KC) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tp.pc[k] = chan[kc * 64 + wave * 8 + k];
+  };
+  auto load_step = [&](int kc, Staged &st, const Taps &tp) {
     u32 neg = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const PwChannel pc = chan[kc * 64 + wave * 8 + k];
-      st.v[k] = base[(size_t)pc.row * row_step + ((i - pc.e) & (N - 1))];
+      const PwChannel pc = tp.pc[k];
+      const u64 *addr = base + (size_t)pc.row * row_step + ((i - pc.e) & (N - 1));
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(st.v[k]) : "v"(addr) : "memory");
       neg |= (i < pc.e ? 1u : 0u) << k;
     }
     st.neg = neg;
     const int u = wave < n_wunits ? wave : 0;   // (every wave loads, so that the value lives in registers; two more store)
-    st.w = w8[(size_t)kc * 1536 + ((u >> 1) * 8 + (u & 1)) * 64 + lane];
+    const uint4 *waddr = w8 + (size_t)kc * 1536 + ((u >> 1) * 8 + (u & 1)) * 64 + lane;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.w) : "v"(waddr) : "memory");
+  };
+  // st's loads have landed once at most `newer` younger loads are outstanding; the "+v" ties keep every use of st behind
+  // the wait
+  auto landed = [&](Staged &st, bool newer_step_in_flight) {
+    if (newer_step_in_flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerStep) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(st.v[k]));
+    asm volatile("" : "+v"(st.w));
   };
   // unit (16 bytes) of digit plane j for this lane's column and this wave's tap group; the wave fills one half of it
   u64 *const out_half = reinterpret_cast<u64 *>(pwn_lds + (lane >> 4) * 64 + (((wave >> 1) << 4) | (lane & 15))) + (wave & 1);
@@ -1153,7 +1211,7 @@ __global__ __launch_bounds__(512, 4) void pw_narrow_kernel(const u64 *__restrict
     };
     planes(lo, 0);
     planes(hi, 4);
-    if (wave < n_wunits) pwn_lds[buf * kStride + 2048 + wave * 64 + lane] = st.w;
+    if (wave < n_wunits) pwn_lds[buf * kStride + 2048 + wave * 64 + lane] = make_uint4(st.w.x, st.w.y, st.w.z, st.w.w);
   };
   // product role: wave (wm, wn) owns filter tile wm and columns 16 wn .. + 15
   const int wm = wave >> 2, wn = wave & 3;
@@ -1183,21 +1241,42 @@ __global__ __launch_bounds__(512, 4) void pw_narrow_kernel(const u64 *__restrict
   };
   // Two steps of loads in flight: step k + 2 is requested before the products of step k, step k + 1 (requested an
   // iteration earlier) is turned into digits behind them.  Staging slots alternate, so the loop runs in pairs.
+  // (a raw barrier behind a wait for this wave's LDS traffic only: __syncthreads() would also drain the global loads
+  // that are meant to stay in flight across it)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   Staged s0, s1;
-  load_step(0, s0);
-  if (KC > 1) load_step(1, s1);
+  Taps t0, t1;
+  fetch_taps(0, t0);
+  fetch_taps(1, t1);
+  load_step(0, s0, t0);
+  fetch_taps(2, t0);
+  if (KC > 1) load_step(1, s1, t1);
+  fetch_taps(3, t1);
+  landed(s0, KC > 1);
   store_step(0, s0);
-  __syncthreads();
+  lds_barrier();
   for (int kc = 0; kc < KC; kc += 2) {
-    if (kc + 2 < KC) load_step(kc + 2, s0);
+    if (kc + 2 < KC) load_step(kc + 2, s0, t0);
+    fetch_taps(kc + 4, t0);
     products(0);
-    if (kc + 1 < KC) store_step(1, s1);   // the other buffer: its readers finished at the last barrier
-    __syncthreads();
+    if (kc + 1 < KC) {   // the other buffer: its readers finished at the last barrier
+      landed(s1, kc + 2 < KC);
+      store_step(1, s1);
+    }
+    lds_barrier();
     if (kc + 1 >= KC) break;
-    if (kc + 3 < KC) load_step(kc + 3, s1);
+    if (kc + 3 < KC) load_step(kc + 3, s1, t1);
+    fetch_taps(kc + 5, t1);
     products(1);
-    if (kc + 2 < KC) store_step(0, s0);
-    __syncthreads();
+    if (kc + 2 < KC) {
+      landed(s0, kc + 3 < KC);
+      store_step(0, s0);
+    }
+    lds_barrier();
   }
   if (!has_tile) return;
   const size_t ocol = c0 + wn * 16 + (lane & 15);
@@ -1213,10 +1292,17 @@ __global__ __launch_bounds__(512, 4) void pw_narrow_kernel(const u64 *__restrict
     if (mrow + r < M) out[(size_t)r * cols] = val;
   }
 }
-// MMH_PW_NARROW=0 keeps layers of at most 32 filters on the digit image (A/B measurements, tests of both forms)
+// MMH_PW_NARROW=0 keeps layers of at most 32 filters on the digit image, =1 sends all of them here (A/B measurements,
+// tests of both forms).  By itself the library takes this kernel when its one workgroup per tile fills the chip or
+// the tap loop is long enough to hide a workgroup's start: with fewer tiles than compute units and at most four steps
+// the two-launch form's full occupancy wins (SqueezeNet's 128 / 256 -> 32 1x1 at 27x27, 150 tiles: 59 against 65 us
+// per layer call; 64 / 128 -> 16 at 56x56, 250 tiles: 52 -> 48 and 60 -> 55 us the other way).
 static bool pw_narrow_ok(const mmh_conv_plan *p) {
   const char *e = getenv("MMH_PW_NARROW");
-  return !(e && e[0] == '0') && p->meta.n_filters <= 32;
+  if (e && e[0] == '0') return false;
+  if (p->meta.n_filters > 32) return false;
+  if (e && e[0] == '1') return true;
+  return (int)p->pw_live_tiles >= p->ctx->n_cu || p->pw_taps_padded >= 8 * 64;
 }
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
@@ -1583,10 +1669,10 @@ extern "C" int mmh_conv_plan_create(const mmh_ctx *ctx, const mmh_conv_meta *met
     const bool never = pw_env && pw_env[0] == '0', always = pw_env && pw_env[0] == '1';
     p->direct_fresh = !never && (always || t_direct < t_fresh);
     p->direct_prepared = !never && (always || t_direct < t_prepared);
-    // Layers of at most 32 filters multiply in one launch that builds its digits itself (pw_narrow_kernel) and beat
-    // the transform route's eight or nine launches at every size measured (128 -> 32 3x3 at 56x56 / 28x28 / 14x14 /
+    // Layers of at most 32 filters multiply in one launch that builds its digits itself (pw_narrow_kernel) or in the
+    // two launches of the digit image, and either beats the transform route's eight or nine launches at every size measured (128 -> 32 3x3 at 56x56 / 28x28 / 14x14 /
     // 7x7: 88 / 80 / 74 / 75 us against 328 / 133 / 92 / 82 us per layer call; 256 -> 32 1x1 at 27x27: 56 against 167)
-    if (!never && pw_narrow_ok(p) && pw_mfma_enabled(ctx)) p->direct_fresh = p->direct_prepared = true;
+    if (!never && meta->n_filters <= 32 && pw_mfma_enabled(ctx)) p->direct_fresh = p->direct_prepared = true;
   }
   std::vector<u32> kept_idx, kept_off(p->n_spatial + 1, 0);
   std::vector<int> kept_rank(p->n_spatial * (size_t)N, -1);
@@ -1701,12 +1787,17 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
                             const uint64_t *d_flood = nullptr, const int64_t *d_e0 = nullptr,
                             const mmh_conv_filters *prepared = nullptr, const uint64_t *d_share_raw = nullptr,
                             uint32_t *d_zero_filter = nullptr, const uint64_t *d_zero_enc = nullptr,
-                            void *verdict_event = nullptr) {
+                            void *verdict_event = nullptr, const uint32_t *draw_key = nullptr, uint64_t draw_sid = 0,
+                            size_t draw_first = 0) {
+  // draw_key: the call draws u, e1 and the mask itself -- polynomials [draw_first, draw_first + n_out) of the streams
+  // mmh_sample_reshare(key, draw_sid) makes -- instead of taking them as arrays (d_u, d_e1, d_mask null)
   const bool exact = d_flood != nullptr;  // USE_APPROX_RESHARE=0 build
   MMH_REQUIRE(!exact || d_e0, MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!prepared || prepared->plan == p, MMH_ERR_INVALID_ARG);
-  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw || prepared) && ((d_pk_ntt_last && d_u) || d_zero_enc) &&
-                  d_e1 && d_mask && d_out_cts && d_out_share,
+  MMH_REQUIRE(!draw_key || (!exact && !d_zero_enc && !d_u && !d_e1 && !d_mask), MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(p && d_in_cts && (d_filter_pts || d_filters_raw || prepared) &&
+                  ((d_pk_ntt_last && (d_u || draw_key)) || d_zero_enc) && ((d_e1 && d_mask) || draw_key) && d_out_cts &&
+                  d_out_share,
               MMH_ERR_NULL_POINTER);
   MMH_REQUIRE(!d_zero_enc || !exact, MMH_ERR_INVALID_ARG);
   MMH_REQUIRE(!p->meta.is_shared_input || d_share_pts || d_share_raw, MMH_ERR_DIM_MISMATCH);  // conv2DSS :633-637
@@ -1717,12 +1808,13 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   void *image = nullptr, *acc = nullptr, *zero = nullptr, *f_ntt = nullptr, *mask_t = nullptr;
   void *wp = nullptr, *wl = nullptr, *w8 = nullptr, *anymap = nullptr;   // weight forms of a fresh direct-route call
   void *u_ntt = nullptr;                                                  // u of the tail, transformed by the front launch
+  void *dr_u = nullptr, *dr_e1 = nullptr, *dr_mask = nullptr, *dr_zero = nullptr;   // a drawing call's own randomness
   void *flag_word = nullptr;   // the direct route's weight-form flag, cleared by the kernel that builds the image
   // the route: prepared filters carry the one they were prepared for
   const bool direct = prepared ? prepared->w8 != nullptr : p->direct_fresh;
   int rc = MMH_OK;
   auto cleanup = [&]() {
-    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word, wp, wl, w8, anymap, u_ntt})
+    for (void *b : {image, acc, zero, f_ntt, mask_t, flag_word, wp, wl, w8, anymap, u_ntt, dr_u, dr_e1, dr_mask, dr_zero})
       if (b) (void)scratch_free(b, s);
   };
   auto grab = [&](void **b, size_t bytes) {
@@ -1743,6 +1835,20 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // (with prepared filters the launch has no weight part: image and u's transform)
   const bool front = via_image_kernel && direct && (prepared || d_filters_raw) && pw_mfma_enabled(ctx);
   const bool nz_inline = d_zero_filter && front && !prepared;
+  // A drawing call: where the front launch exists and the tail's u is transformed there, the draws happen inside it
+  // (FrontDraw); elsewhere one sampling launch makes the arrays here and the call goes on as if they had been passed
+  const bool draw_in_front = draw_key && front && ctx->h_mods[0].fold_c != 0 && !ctx->h_mods[0].f64;
+  const bool draw_zero = draw_in_front && ctx->logN == 12 && p->n_out <= reshare_split_max();
+  if (draw_key) {
+    grab(&dr_e1, p->n_out * N * 8);
+    grab(&dr_mask, p->n_out * N * 8);
+    if (!draw_in_front) grab(&dr_u, p->n_out * N * 8);
+    if (draw_zero) grab(&dr_zero, p->n_out * 2 * N * 8);
+    if (!rc && !draw_in_front)
+      rc = mmh_sample_reshare_range(ctx, draw_key, draw_sid, draw_first, p->n_out, (int64_t *)dr_u, (int64_t *)dr_e1,
+                                    (u64 *)dr_mask, stream);
+    d_u = (const int64_t *)dr_u, d_e1 = (const int64_t *)dr_e1, d_mask = (const u64 *)dr_mask;
+  }
   PwFold fold{nullptr, 0, nullptr, nullptr, 0, 0};
   if (!rc && front) {
     const PwSizes z = pw_sizes(p);
@@ -1759,23 +1865,37 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
         fold = PwFold{(const u32 *)flag_word + 1, (int)n_w, (u32 *)flag_word, (const uint8_t *)anymap, z.Cpad64 / 16, z.Mpad128};
       // u's transform rides along when the tail will want it (approximate build, q0 of the folding shape)
       const bool with_u = !exact && !d_zero_enc && ctx->h_mods[0].fold_c != 0 && !ctx->h_mods[0].f64;
-      if (with_u) grab(&u_ntt, p->n_out * N * 8);
-      const unsigned n_u = with_u && !rc ? (unsigned)p->n_out : 0;
+      if (with_u && !draw_zero) grab(&u_ntt, p->n_out * N * 8);
+      const unsigned n_u = with_u && !rc ? (unsigned)p->n_out * (draw_zero ? 2u : 1u) : 0;
       NttSource usrc{};
       usrc.p = reinterpret_cast<const u64 *>(d_u);
+      FrontDraw dr{};
+      unsigned n_draw = 0;
+      if (draw_in_front) {
+        for (int i = 0; i < 8; ++i) usrc.key.k[i] = draw_key[i];
+        usrc.sid = draw_sid, usrc.first_tile = draw_first * (N / 4096);
+        const size_t first = draw_first * N, total = p->n_out * N;
+        auto lo = [&](int per) { return (unsigned)(first / (256 * (size_t)per)); };
+        auto cnt = [&](int per) { return (unsigned)((first + total + 256 * (size_t)per - 1) / (256 * (size_t)per)) - lo(per); };
+        dr.mode = draw_zero ? 2 : 1, dr.pk = d_pk_ntt_last, dr.zero = (u64 *)dr_zero;
+        dr.e1 = (int64_t *)dr_e1, dr.mask = (u64 *)dr_mask;
+        dr.n_e = cnt(kNoisePerBlock), dr.n_m = cnt(kUniformPerBlock), dr.lo_e = lo(kNoisePerBlock), dr.lo_m = lo(kUniformPerBlock);
+        dr.first = first, dr.total = total;
+        n_draw = dr.n_e + dr.n_m;
+      }
       const PwWeightArgs wa = pw_weight_args(p, d_filters_raw, (u32 *)wp, (u64 *)wl, (uint8_t *)w8);
       if (!rc && ctx->logN == 12)
-        hipLaunchKernelGGL(conv_front_kernel<12>, dim3(n_u + n_img + n_w), dim3(256), lds_bytes<12>(), s, img_args, ctx->bfv,
-                           ctx->d_mods, n_u, n_img, wa, flag_word ? (u32 *)flag_word + 1 : nullptr, (uint8_t *)anymap,
-                           d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables);
+        hipLaunchKernelGGL(conv_front_kernel<12>, dim3(n_u + n_img + n_w + n_draw), dim3(256), lds_bytes<12>(), s, img_args,
+                           ctx->bfv, ctx->d_mods, n_u, n_img, wa, flag_word ? (u32 *)flag_word + 1 : nullptr, (uint8_t *)anymap,
+                           d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables, n_w, dr);
       else if (!rc && ctx->logN == 13) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_front_kernel<13>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<13>()) != hipSuccess)
           rc = MMH_ERR_INTERNAL;
         if (!rc)
-          hipLaunchKernelGGL(conv_front_kernel<13>, dim3(n_u + n_img + n_w), dim3(256), lds_bytes<13>(), s, img_args,
+          hipLaunchKernelGGL(conv_front_kernel<13>, dim3(n_u + n_img + n_w + n_draw), dim3(256), lds_bytes<13>(), s, img_args,
                              ctx->bfv, ctx->d_mods, n_u, n_img, wa, flag_word ? (u32 *)flag_word + 1 : nullptr,
-                             (uint8_t *)anymap, d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables);
+                             (uint8_t *)anymap, d_zero_filter, (u64 *)u_ntt, usrc, ctx->d_tables, n_w, dr);
       } else if (!rc) {
         rc = MMH_ERR_CONFIG;
       }
@@ -1836,6 +1956,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && !exact) {
     // addRandomMask :761-788 (mod-switch, pk-encryption of zero without e0, RNS mask), truncation
     // :698-703 and removeUnusedCoeffs :800-851 as one fused tail; the share is the mask's scale-and-round
+    if (draw_zero) d_zero_enc = (const u64 *)dr_zero;   // made by the front launch: the tail is its one-thread-per-coefficient half
     rc = d_zero_enc
              ? reshare_tail_online(ctx, (u64 *)acc, !direct, p->n_out, d_zero_enc, d_e1, d_mask, p->d_keep, S, d_out_cts,
                                    s, p->d_share_dst, (size_t)(p->out_h * p->out_w), d_out_share, sw_acc)
@@ -1920,6 +2041,20 @@ extern "C" int mmh_conv_server_tensors_ev(const mmh_conv_plan *p, const uint64_t
   return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, d_u, d_e1, d_mask, d_out_cts,
                           d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr,
                           zero_filter, nullptr, verdict_event);
+}
+
+extern "C" int mmh_conv_server_tensors_sampled(const mmh_conv_plan *p, const uint64_t *d_in_cts, const uint64_t *d_share,
+                                               const uint64_t *d_filters, const uint64_t *d_pk_ntt_last,
+                                               const uint32_t key[8], uint64_t stream_id, size_t first_poly,
+                                               uint64_t *d_out_cts, uint64_t *d_out_share, uint32_t *zero_filter,
+                                               void *verdict_event, void *stream) {
+  MMH_DEVICE_SCOPE(p ? p->ctx : nullptr);
+  MMH_REQUIRE(p && d_filters && key, MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(!p->meta.is_shared_input || d_share, MMH_ERR_DIM_MISMATCH);
+  MMH_REQUIRE(!verdict_event || zero_filter, MMH_ERR_INVALID_ARG);
+  return conv_server_impl(p, d_in_cts, nullptr, nullptr, d_filters, d_pk_ntt_last, nullptr, nullptr, nullptr, d_out_cts,
+                          d_out_share, stream, nullptr, nullptr, nullptr, p->meta.is_shared_input ? d_share : nullptr,
+                          zero_filter, nullptr, verdict_event, key, stream_id, first_poly);
 }
 
 extern "C" int mmh_conv_filters_destroy(mmh_conv_filters *f) {

@@ -4,6 +4,7 @@
 #pragma once
 #include "common.hpp"
 #include "bfv_device.hpp"
+#include "sampler_device.hpp"
 
 namespace mmh {
 
@@ -206,7 +207,11 @@ __device__ __forceinline__ void inv_radix_f64(double (&x)[1 << R], const double 
 //   SRC_SIGNED   small signed polynomials `src.p` [n_polys][N] (int64: ternary u, noise), mapped to
 //                [0, q) per limb on load (sample_poly_ternary / SEAL_NOISE_SAMPLER outputs as
 //                encrypt_zero consumes them, hom_conv2d_ss.cc:302-306).
-enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3 };
+//   SRC_TERNARY  the ternary u of an encryption of zero DRAWN IN PLACE: polynomial k is tile first_tile + k of the
+//                ternary stream (key, sid) of sampler_device.hpp -- thread t's 16 samples of a tile are exactly the
+//                coefficients 256 j + t it transforms -- so u never exists in memory; the same values as
+//                mmh_sample_ternary / mmh_sample_reshare followed by SRC_SIGNED.
+enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3, SRC_TERNARY = 4 };
 struct NttSource {
   const u64 *p;
   const u64 *p2;                   // inverse transform of a product: the key pair [2][limbs][N] (p = [n][limbs][N])
@@ -219,6 +224,8 @@ struct NttSource {
   u64 t_bhi, t_blo;                // Barrett constants of t (SRC_FILTER reduces the raw weights)
   int C, taps, wc, n_cslices;      // channels, fh*fw, channels per slice, slices per filter
   int fw, origin, plane, row;      // coefficient = origin - cc*plane - r*row - col
+  ChaChaKey key;                   // SRC_TERNARY: the sampler's key, the ternary stream's id and the tile of polynomial 0
+  u64 sid, first_tile;
 };
 
 // The EA = N/256 stride-256 coefficients of thread t, from wherever the transform reads them.
@@ -227,7 +234,15 @@ __device__ __forceinline__ void load_source(u32 unit, u64 (&x)[1 << (LOGN - 8)],
                                             const DevMod &M, const NttSource &src, int limbs, u64 *lds) {
   constexpr int EA = 1 << (LOGN - 8);
   const int t = threadIdx.x;
-  if (SRC == SRC_PLAIN) {
+  if (SRC == SRC_TERNARY) {
+#pragma unroll
+    for (int h = 0; h < EA / 16; ++h) {
+      int64_t v[16];
+      ternary_samples(src.key, src.sid, src.first_tile + (size_t)(unit / limbs) * (EA / 16) + h, t, v);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[h * 16 + k] = v[k] >= 0 ? (u64)v[k] : M.q - (u64)(-v[k]);
+    }
+  } else if (SRC == SRC_PLAIN) {
     const u64 *__restrict__ m = src.p + (size_t)(unit / limbs) * (1 << LOGN);
     const u64 up = M.q - src.t;
 #pragma unroll
@@ -387,6 +402,92 @@ __device__ __forceinline__ void ntt_fwd_unit(u32 unit, u64 *__restrict__ data, c
   }
   __syncthreads();
   store_from_lds<LOGN>(a, lds);
+}
+
+// N = 4096, one integer limb of the 2^b - c shape: component j of the pk-encryption of zero of the re-sharing
+// (asymmetric_encrypt_zero, hom_conv2d_ss.cc:302-316: u drawn, transformed, multiplied by pk_j, transformed back) in
+// ONE workgroup, nothing but the result written.  The forward transform's last pass and the inverse transform's first
+// work on the same 16 consecutive coefficients of a lane, so the product with the key happens in registers between
+// them.  Same canonical values as SRC_TERNARY -> ntt_inv_kernel<PROD>: out = INTT(NTT(u) (.) key).
+template <bool FOLD>
+__device__ __forceinline__ void ntt_zero_unit12(u32 poly, const DevMod &M, const ulonglong2 *__restrict__ tables,
+                                                const NttSource &src, const u64 *__restrict__ key,
+                                                u64 *__restrict__ out, u64 *lds) {
+  constexpr int LOGN = 12, N = 1 << LOGN;
+  const int t = threadIdx.x;
+  const ulonglong2 *__restrict__ tw = tables + M.tw_offset, *__restrict__ twi = tw + N;
+  const Reducer<FOLD> rd(M);
+  const u64 nq = M.nq;
+  {
+    ulonglong2 wB[15];
+    {
+      u64 x[16];
+      load_source<LOGN, SRC_TERNARY>(poly, x, nullptr, M, src, 1, lds);
+      ulonglong2 wA[15];
+      load_twiddles<4, 0>(tw, 0, wA);
+      load_twiddles<4, 4>(tw, t >> 4, wB);
+      fwd_radix<4, 0, FOLD, true>(x, wA, nq, rd);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) lds[pad(k * 256 + t)] = x[k];
+    }
+    __syncthreads();
+    {
+      const int jhi = t >> 4, jlo = t & 15;
+      u64 x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
+      fwd_radix<4, 4, FOLD>(x, wB, nq, rd);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
+    }
+  }
+  __syncthreads();
+  ulonglong2 iB[15];
+  {
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[17 * t + k];
+    {
+      ulonglong2 wC[15];
+      load_twiddles<4, 8>(tw, t, wC);
+      fwd_radix<4, 8, FOLD>(x, wC, nq, rd);
+    }
+    const ulonglong2 *__restrict__ kv = reinterpret_cast<const ulonglong2 *>(key) + 8 * t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // coefficients 16 t + 2k, + 2k + 1 of NTT(u), times the key's
+      const ulonglong2 w = kv[k];
+      x[2 * k] = mul_mod_fold(rd.fwd_final(x[2 * k]), w.x, M);
+      x[2 * k + 1] = mul_mod_fold(rd.fwd_final(x[2 * k + 1]), w.y, M);
+    }
+    ulonglong2 iC[15];
+    load_twiddles<4, 8>(twi, t, iC);
+    load_twiddles<4, 4>(twi, t >> 4, iB);
+    inv_radix<4, 8, 0, FOLD>(x, iC, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[17 * t + k] = x[k];   // (the cells this lane just read: no barrier before)
+  }
+  __syncthreads();
+  {
+    const int jhi = t >> 4, jlo = t & 15;
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(jhi * 256 + k * 16 + jlo)];
+    inv_radix<4, 4, 4, FOLD>(x, iB, nq, rd);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad(jhi * 256 + k * 16 + jlo)] = x[k];
+  }
+  __syncthreads();
+  {
+    u64 x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[pad(k * 256 + t)];
+    ulonglong2 wA[15];
+    load_twiddles<4, 0>(twi, 0, wA);
+    inv_radix<4, 0, 8, FOLD, true>(x, wA, nq, rd);
+    const u64 ninv = M.ninv, ninv_sh = M.ninv_sh;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k * 256 + t] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
+  }
 }
 
 template <int LOGN>

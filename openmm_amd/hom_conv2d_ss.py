@@ -242,7 +242,9 @@ class HomConv2DSS:
         in device memory and read when the whole call has run.  defer_verdict: the call returns without waiting at
         all and the verdict is read by raise_pending() behind the caller's own synchronisation -- what the C++ host
         does (it synchronises once per layer anyway, before the send: openmm_amd/host/cheetah_linear.cc) and what a
-        caller that enqueues many layers ahead wants; at most 256 calls may be pending."""
+        caller that enqueues many layers ahead wants; at most 256 calls may be pending.
+        rand: (u, e1, mask) tensors, or an openmm_amd.lib.Sampler: the call then draws the three itself, from the next
+        three streams of that sampler -- the same values sampler.reshare(n_out) would have returned."""
         self._need(self.pk_ntt is not None, 1, "conv2DSS: no public key")
         self._need(filters.shape[0] > 0 and filters.shape[0] == meta.n_filters, 7, "encodeFilters: #filters")
         self._need(tuple(filters.shape[1:]) == tuple(meta.fshape), 3, "encodeFilters: filter shape")
@@ -253,8 +255,10 @@ class HomConv2DSS:
                        "encodeImage: image shape")
             share_tensor = share_tensor.contiguous()
         filters = filters.contiguous()
-        self._check_rand(p, rand, ("u", "e1", "mask"))
-        u, e1, mask = rand
+        drawn = isinstance(rand, L.Sampler)   # the call draws u, e1 and the mask itself (mmh_conv_server_tensors_sampled)
+        if not drawn:
+            self._check_rand(p, rand, ("u", "e1", "mask"))
+            u, e1, mask = rand
         if out is None:
             out_cts = self.ctx._empty(p.n_out, 2, 1, self.ctx.N)
             out_share = self.ctx._empty(*p.out_shape)
@@ -263,7 +267,20 @@ class HomConv2DSS:
             self._need(tuple(out_cts.shape) == (p.n_out, 2, 1, self.ctx.N) and tuple(out_share.shape) == p.out_shape,
                        3, "conv2DSS: output buffers")
         share_ptr = L.dptr(share_tensor if meta.is_shared_input else None)
-        if inline_verdict:
+        if drawn:
+            if self._verdicts is None:
+                self._verdicts = L.VerdictRing(256)
+            self._need(len(self._pending) < 255, 5, "conv2DSS: too many deferred verdicts, call raise_pending()")
+            slot, word, event = self._verdicts.take()
+            L.check(self.ctx.lib.mmh_conv_server_tensors_sampled(p.handle, L.dptr(img_share0), share_ptr, L.dptr(filters),
+                                                                 L.dptr(self.pk_last), rand.key, rand.reshare_streams(), 0,
+                                                                 L.dptr(out_cts), L.dptr(out_share), word, event,
+                                                                 L._stream_ptr()))
+            if defer_verdict:
+                self._pending.append(slot)
+                return out_cts, out_share
+            nz = self._verdicts.read(slot) == 0
+        elif inline_verdict:
             bad = torch_empty_flag(filters)   # zero-filter verdict, known when the whole call has run
             L.check(self.ctx.lib.mmh_conv_server_tensors(p.handle, L.dptr(img_share0), share_ptr, L.dptr(filters),
                                                          L.dptr(self.pk_last), L.dptr(u), L.dptr(e1), L.dptr(mask),

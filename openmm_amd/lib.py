@@ -103,6 +103,7 @@ SIGNATURES = {
     "mmh_conv_server_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server_tensors": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_conv_server_tensors_ev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mmh_conv_server_tensors_sampled": [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32), _u64, _sz, _vp, _vp, _vp, _vp, _vp],
     "mmh_event_create": [C.POINTER(_vp)],
     "mmh_event_destroy": [_vp],
     "mmh_event_record": [_vp, _vp],
@@ -467,6 +468,12 @@ class Sampler:
         check(self.ctx.lib.mmh_sample_reshare(self.ctx.handle, self.key, sid, n_polys, dptr(u), dptr(e1), dptr(mask),
                                               _stream_ptr()))
         return u, e1, mask
+
+    def reshare_streams(self):
+        """the stream id a call that draws a re-sharing's randomness itself should use (three consecutive streams)"""
+        sid = self.next_stream
+        self.next_stream += 3
+        return sid
 
     def reshare_range(self, sid, first_poly, n_polys):
         """polynomials [first_poly, first_poly + n_polys) of the draw reshare() makes on streams sid .. sid + 2"""

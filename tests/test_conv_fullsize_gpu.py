@@ -69,7 +69,7 @@ def check_routes(monkeypatch, L, ishape, M, same, stride, shared, routes=("0", "
         # library pairs a layer when it has enough items, "1p" / "1" force every layer / none (read on every call)
         # layers of at most 32 filters build their digits inside the product kernel by default ("1n"); "1" / "1p" keep
         # them on the digit image
-        for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)), ("MMH_PW_NARROW", {"1": "0", "1p": "0"}.get(route))):
+        for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)), ("MMH_PW_NARROW", {"1": "0", "1p": "0", "1n": "1"}.get(route))):
             if val is None:
                 monkeypatch.delenv(var, raising=False)
             else:

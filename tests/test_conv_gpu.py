@@ -129,7 +129,7 @@ def test_conv_layer_bit_exact(mm, monkeypatch, ishape, fhw, M, same, stride, sha
     # accumulator (the library pairs only layers with enough items by itself: none of these small cases); "1": never
     # "1n": layers of at most 32 filters through the kernel that builds its digits itself (the default for them);
     # "1" and "1p" keep them on the digit image, so that the wide kernel sees these small cases too
-    for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)), ("MMH_PW_NARROW", {"1": "0", "1p": "0"}.get(route))):
+    for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)), ("MMH_PW_NARROW", {"1": "0", "1p": "0", "1n": "1"}.get(route))):
         if val is None:
             monkeypatch.delenv(var, raising=False)
         else:
@@ -417,3 +417,54 @@ def test_layer_calls_on_two_streams_share_the_scratch_cache(mm):
     for k in range(2):
         assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1])
     assert g.lib.mmh_scratch_release() == 0
+
+
+@pytest.mark.parametrize("tail_split_max", [None, "0"])
+@pytest.mark.parametrize("route", ["model", "0", "1", "1p", "1n"])
+@pytest.mark.parametrize("ishape,fhw,M,same,stride,shared", CASES[:6] + [((40, 14, 14), (1, 1), 70, 0, 1, True)])
+def test_conv_call_that_draws_its_own_randomness(mm, monkeypatch, ishape, fhw, M, same, stride, shared, route,
+                                                 tail_split_max, n=None):
+    """mmh_conv_server_tensors_sampled (conv2DSS draws u, e1 and the mask inside the call, hom_conv2d_ss.cc:302,:329,
+    :206): the same ciphertexts and share as the call on the arrays mmh_sample_reshare makes from the same key and
+    streams -- which test_conv_layer_bit_exact pins against the oracle -- on every route, with the tail in its split
+    form (the front launch finishes the encryption of zero) and in its fused form (it leaves u transformed)."""
+    from openmm_amd.hom_conv2d_ss import HomConv2DSS, Meta
+    from openmm_amd.lib import Sampler
+    if route != "model":
+        monkeypatch.setenv("MMH_CONV_POINTWISE", route[0])
+    for var, val in (("MMH_PW_PAIRED", {"1": "0", "1p": "1"}.get(route)),
+                     ("MMH_PW_NARROW", {"1": "0", "1p": "0", "1n": "1"}.get(route)), ("MMH_TAIL_SPLIT_MAX", tail_split_max)):
+        if val is None:
+            monkeypatch.delenv(var, raising=False)
+        else:
+            monkeypatch.setenv(var, val)
+    n = n or N
+    o, g = OracleCtx(n, (60, 49), T), mm.Context(n, (60, 49), T)
+    fshape = (ishape[0],) + tuple(fhw)
+    meta = Meta(ishape, fshape, M, same, stride, shared)
+    _, pk = keypair(o)
+    server = HomConv2DSS()
+    server.setUp(g, pk_ntt=dev(pk))
+    plan = server.plan(meta)
+    cts = dev(np.stack([rns_uniform(o, SEED + 70 + k, plan.n_in, 2) for k in range(2)], axis=1))   # [n_in][2][L][N]
+    share = dev(uniform_mod(SEED + 75, ishape, T)) if shared else None
+    filters = dev(signed_weights(SEED + 72, (M,) + fshape, 1 << 12, T))
+    key = bytes(range(7, 39))
+    a = Sampler(g, key)
+    a.words(5)                                # (streams already spent: the call must take the sampler's NEXT three)
+    ref_out, ref_share = server.conv2DSSFromTensors(cts, share, filters, meta, a.reshare(plan.n_out))
+    b = Sampler(g, key)
+    b.words(5)
+    got_out, got_share = server.conv2DSSFromTensors(cts, share, filters, meta, b)
+    assert np.array_equal(host(got_out), host(ref_out)) and np.array_equal(host(got_share), host(ref_share))
+    assert b.next_stream == a.next_stream
+    # deferred verdict form
+    got_out, got_share = server.conv2DSSFromTensors(cts, share, filters, meta, Sampler(g, key), defer_verdict=True)
+    import torch
+    torch.cuda.synchronize()
+    server.raise_pending()
+
+
+def test_conv_call_that_draws_its_own_randomness_n8192(mm, monkeypatch):
+    test_conv_call_that_draws_its_own_randomness(mm, monkeypatch, (9, 20, 20), (3, 3), 5, 1, 1, True, "1", None, n=8192)
+    test_conv_call_that_draws_its_own_randomness(mm, monkeypatch, (40, 14, 14), (1, 1), 70, 0, 1, True, "model", "0", n=8192)

@@ -55,10 +55,14 @@ int main(int argc, char **argv) {
   uint32_t key[8] = {1, 2, 3, 4, 5, 6, 7, 8};
   uint64_t sid = 1;
   auto run = [&]() -> int {
+    // MM_LAYER_ARRAYS=1: the randomness as arrays from one sampling launch, then the call; else the call draws it itself
+    static const bool arrays = getenv("MM_LAYER_ARRAYS") != nullptr;
+    sid += 3;
+    if (!arrays)
+      return mmh_conv_server_tensors_sampled(plan, d_cts, meta.is_shared_input ? d_share : nullptr, d_filt, d_pk, key, sid, 0,
+                                             d_out, d_osh, nullptr, nullptr, nullptr);
     int rc;
-    if ((rc = mmh_sample_ternary(key, sid++, (int64_t *)d_u, n_out * N, nullptr))) return rc;
-    if ((rc = mmh_sample_noise(key, sid++, (int64_t *)d_e1, n_out * N, nullptr))) return rc;
-    if ((rc = mmh_sample_uniform(ctx, 1, key, sid++, d_mask, n_out, nullptr))) return rc;
+    if ((rc = mmh_sample_reshare(ctx, key, sid, n_out, (int64_t *)d_u, (int64_t *)d_e1, d_mask, nullptr))) return rc;
     return mmh_conv_server_tensors(plan, d_cts, meta.is_shared_input ? d_share : nullptr, d_filt, d_pk, (const int64_t *)d_u,
                                    (const int64_t *)d_e1, d_mask, d_out, d_osh, nullptr, nullptr);
   };
