@@ -266,13 +266,12 @@ Code HomConv2DSS::conv2DSS(const std::vector<seal::Ciphertext> &img_share0, cons
   std::uint32_t key[8];
 #if USE_APPROX_RESHARE
   const std::uint64_t sid = f->streams(key, 3);
-  DI_TRY(mmh_sample_reshare(f->ctx, key, sid, pi.n_out, (std::int64_t *)u.p, (std::int64_t *)e1.p, mask.p, f->stream));
   const bool raw_share = !meta.is_shared_input || ib;
   if (fb && raw_share) {
-    // encodeImage + encodeFilters + conv2DSS from the raw tensors (mmh_conv_server_tensors)
-    DI_TRY(mmh_conv_server_tensors(pi.plan, cts.p, ib ? ib->raw.p : nullptr, fb->raw.p, f->pk_last.p,
-                                   (const std::int64_t *)u.p, (const std::int64_t *)e1.p, mask.p, out_cts.p, share.p,
-                                   nullptr, f->stream));
+    // encodeImage + encodeFilters + conv2DSS from the raw tensors, the re-sharing's u, e1 and mask drawn inside the call
+    // from streams sid .. sid + 2 (mmh_conv_server_tensors_sampled = mmh_sample_reshare + mmh_conv_server_tensors)
+    DI_TRY(mmh_conv_server_tensors_sampled(pi.plan, cts.p, ib ? ib->raw.p : nullptr, fb->raw.p, f->pk_last.p, key, sid, 0,
+                                           out_cts.p, share.p, nullptr, nullptr, f->stream));
   } else
 #endif
   {
@@ -310,6 +309,7 @@ Code HomConv2DSS::conv2DSS(const std::vector<seal::Ciphertext> &img_share0, cons
       d_fpts = fpts.p;
     }
 #if USE_APPROX_RESHARE
+    DI_TRY(mmh_sample_reshare(f->ctx, key, sid, pi.n_out, (std::int64_t *)u.p, (std::int64_t *)e1.p, mask.p, f->stream));
     DI_TRY(mmh_conv_server(pi.plan, cts.p, d_spts, d_fpts, f->pk_last.p, (const std::int64_t *)u.p,
                            (const std::int64_t *)e1.p, mask.p, out_cts.p, share.p, f->stream));
 #else
