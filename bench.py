@@ -482,9 +482,7 @@ class NetworkLegs:
         """ALICE's side of one ElemWiseActModelVectorMult on n elements (see the class comment); the client's
         ciphertexts, Ferret's blocks for the two COTs and the model's scale vector (already getFieldElt'ed) resident"""
         import ctypes as C
-        from openmm_amd.hom_bn_ss import Meta as BnMeta
         torch, L, lib, p, l, N = self.torch, self.L, self.lib, FIELD_PRIME, RING_BITS, self.N
-        meta = BnMeta((n,), p, True)
         n_ct = (n + N - 1) // N
         x = self.rnd(0, self.t, n)
         scale = self.rnd(0, p, n)
@@ -492,8 +490,6 @@ class NetworkLegs:
         rcm = [self.rnd(-(1 << 62), 1 << 62, n, 2) for _ in range(2)]
         two = (C.c_uint64 * 2)
         delta, seed = two(0x0123456789ABCDEF, 0xFEDCBA9876543211), two(0x1122334455667788, 0x99AABBCCDDEEFF00)
-        tmp, corr, y, out = (torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(4))
-        msb = torch.empty(n, dtype=torch.uint8, device="cuda")
         wires = []
         for prime in (1, 0):
             nb = C.c_size_t()
@@ -501,17 +497,21 @@ class NetworkLegs:
             wires.append(torch.empty((nb.value + 7) // 8, dtype=torch.int64, device="cuda"))
         gids = C.c_uint64()
         L.check(lib.mmh_cot_gids(n, C.byref(gids)))
+        h = self.bn.ctx.handle
 
         def call():
             s = L._stream_ptr()
-            # Ring2Field, ALICE = COT sender (truncation.cpp:518-581; silent_ot.h:129-163): pre step, the sender's
-            # post-processing and the post step feeding encodeVector in one launch + BatchEncoder's transform
-            in_pts = torch.empty(n_ct, N, dtype=torch.int64, device="cuda")
-            L.check(lib.mmh_cot_send_r2f_encode(self.bn.ctx.handle, L.dptr(rcm[0]), delta, seed, self.gid, L.dptr(x), n, l,
-                                                L.dptr(in_pts), L.dptr(wires[0]), s))
+            # what needs no ciphertext (four launches): Ring2Field with ALICE as the COT sender (truncation.cpp:518-581;
+            # silent_ot.h:129-163) into encodeVector's plaintexts, the scales' plaintexts, addMask's r drawn in place
+            pts3 = torch.empty(3, n_ct, N, dtype=torch.int64, device="cuda")
+            share, out = (torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(2))
+            out_cts = torch.empty(n_ct, 2, N, dtype=torch.int64, device="cuda")
+            L.check(lib.mmh_bn_alice_prepare(h, L.dptr(rcm[0]), delta, seed, self.gid, L.dptr(x), n, l, L.dptr(scale),
+                                             self.sampler.key, self.sampler._sid(), L.dptr(pts3), L.dptr(share),
+                                             L.dptr(wires[0]), s))
             self.gid += gids.value
-            sc_pts = self.bn.encodeScales(scale, meta)
-            out_cts, share = self.bn.bn(cts, in_pts, sc_pts, meta, self.sampler.words(n))   # r drawn here
+            # HomBNSS::bn on the client's ciphertexts (three launches)
+            L.check(lib.mmh_bn_alice_finish(h, L.dptr(cts), L.dptr(pts3), n, L.dptr(out_cts), s))
             # Field2Ring_with_Truncate on her share (truncation.cpp:639-695; silent_ot.h:85-127), one launch
             L.check(lib.mmh_cot_send_f2r(L.dptr(rcm[1]), delta, seed, self.gid, L.dptr(share), n, p, l, K_SCALE,
                                          L.dptr(out), L.dptr(wires[1]), s))

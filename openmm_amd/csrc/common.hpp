@@ -286,6 +286,7 @@ struct mmh_ctx {
   mmh::DevMod h_mods[mmh::kMaxLimbs + 1];
   mmh::BfvConsts bfv;              // valid when t >= 2
   uint32_t *d_slot_map = nullptr;  // BatchEncoder index map (batching only)
+  mmh::BfvConsts *d_bfv = nullptr; // bfv again, in device memory (kernels that take it by pointer: ntt_device.hpp SRC_CT_PLAIN)
   std::vector<void *> allocs;
 };
 namespace mmh {

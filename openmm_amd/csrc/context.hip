@@ -284,6 +284,11 @@ extern "C" int mmh_ctx_create(mmh_ctx **out, size_t N, const uint64_t *q, size_t
     rc = upload(ctx, ctx->h_mods, n_mods * sizeof(DevMod), &d);
     ctx->d_mods = (DevMod *)d;
   }
+  if (!rc && t > 1) {
+    void *d = nullptr;
+    rc = upload(ctx, &ctx->bfv, sizeof(BfvConsts), &d);
+    ctx->d_bfv = (BfvConsts *)d;
+  }
   if (rc) {
     mmh_ctx_destroy(ctx);
     return rc;

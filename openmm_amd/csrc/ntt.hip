@@ -38,6 +38,21 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(u64 *__restrict__ data,
   ntt_fwd_unit<LOGN, FOLD, SRC>(limb_major_unit(limbs), data, mods, tables, limbs, mod_base, src, lds);
 }
 
+// The two operands of HomBNSS::bn's multiply_plain to NTT form in one launch (hom_bn_ss.cc:263-267): units
+// [0, n_ct_units) are the client's ciphertexts with the server's share added on load (SRC_CT_PLAIN, written to `sum`),
+// the rest lift the scale plaintexts (SRC_PLAIN, written to `pt_ntt`).
+template <int LOGN, bool FOLD>
+__global__ __launch_bounds__(256) void bn_front_kernel(u64 *__restrict__ sum, u64 *__restrict__ pt_ntt,
+                                                       const DevMod *__restrict__ mods,
+                                                       const ulonglong2 *__restrict__ tables, int limbs,
+                                                       NttSource ct_src, NttSource pt_src, unsigned n_ct_units) {
+  extern __shared__ __align__(16) u64 lds[];
+  if (blockIdx.x < n_ct_units)
+    ntt_fwd_unit<LOGN, FOLD, SRC_CT_PLAIN>(blockIdx.x, sum, mods, tables, limbs, 0, ct_src, lds);
+  else
+    ntt_fwd_unit<LOGN, FOLD, SRC_PLAIN>(blockIdx.x - n_ct_units, pt_ntt, mods, tables, limbs, 0, pt_src, lds);
+}
+
 // ---------------------------------------------------------------- N = 8192 with 512 threads
 // The 256-thread kernels hold 32 coefficients per lane at N = 8192 and their 68 KiB image lets two workgroups share a
 // CU: two waves per SIMD, too few to cover the latency of the passes.  These hold 16 per lane in 512 threads (four
@@ -719,6 +734,37 @@ int ntt_lift_dispatch(const mmh_ctx *ctx, const u64 *d_src, u64 *d_out, size_t n
   NttSource src{};
   src.p = d_src, src.t = ctx->t, src.thr = ctx->bfv.thr;
   return dispatch(ctx, SRC_PLAIN, d_out, src, n_polys, limbs, 0, s);
+}
+
+// sum[k][j][l] = NTT_l(cts[k][j][l] + [j = 0] round(Q share[k] / t)), pt_ntt[k][l] = NTT_l(lift_l(scales[k])) at the
+// first level, one launch (bn_front_kernel)
+template <int LOGN>
+static int bn_front_launch(const mmh_ctx *ctx, bool fold, u64 *d_sum, u64 *d_pt_ntt, const NttSource &cs,
+                           const NttSource &ps, size_t n, hipStream_t s) {
+  auto kern = fold ? bn_front_kernel<LOGN, true> : bn_front_kernel<LOGN, false>;
+  const int limbs = (int)ctx->L;
+  if (lds_bytes<LOGN>() > 48 * 1024)
+    MMH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes<LOGN>()));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n * 3 * limbs)), dim3(256), lds_bytes<LOGN>(), s, d_sum, d_pt_ntt, ctx->d_mods,
+                     ctx->d_tables, limbs, cs, ps, (unsigned)(n * 2 * limbs));
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+int ntt_bn_front_dispatch(const mmh_ctx *ctx, const u64 *d_cts, const u64 *d_share_pts, const u64 *d_scale_pts, size_t n,
+                          u64 *d_sum, u64 *d_pt_ntt, hipStream_t s) {
+  if (n == 0) return MMH_OK;
+  MMH_REQUIRE(ctx->d_bfv && n * 3 * ctx->L <= 0x7fffffffu, MMH_ERR_OUT_BOUND);
+  NttSource cs{}, ps{};
+  cs.p = d_cts, cs.p2 = d_share_pts, cs.bfv = ctx->d_bfv;
+  ps.p = d_scale_pts, ps.t = ctx->t, ps.thr = ctx->bfv.thr;
+  bool fold = true;
+  for (size_t l = 0; l < ctx->L; ++l) fold = fold && ctx->h_mods[l].fold_c != 0;
+  switch (ctx->logN) {
+    case 12: return bn_front_launch<12>(ctx, fold, d_sum, d_pt_ntt, cs, ps, n, s);
+    case 13: return bn_front_launch<13>(ctx, fold, d_sum, d_pt_ntt, cs, ps, n, s);
+    default: MMH_FAIL(MMH_ERR_CONFIG, "only N = 4096 and N = 8192 are built");
+  }
 }
 
 // out[k][l] = NTT_l(src[k] mod q_l) for the first `limbs` moduli, src [n_polys][N] signed

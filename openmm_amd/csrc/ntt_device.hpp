@@ -211,7 +211,10 @@ __device__ __forceinline__ void inv_radix_f64(double (&x)[1 << R], const double 
 //                ternary stream (key, sid) of sampler_device.hpp -- thread t's 16 samples of a tile are exactly the
 //                coefficients 256 j + t it transforms -- so u never exists in memory; the same values as
 //                mmh_sample_ternary / mmh_sample_reshare followed by SRC_SIGNED.
-enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3, SRC_TERNARY = 4 };
+//   SRC_CT_PLAIN ciphertexts `src.p` [n][2][limbs][N] at the first level with the plaintexts `src.p2` [n][N] (mod t)
+//                added on load the way Evaluator::add_plain does (round(q m / t) onto c0, every limb), so the sum
+//                never exists in coefficient form (HomBNSS::bn, hom_bn_ss.cc:263-265, in front of multiply_plain).
+enum { SRC_INPLACE = 0, SRC_PLAIN = 1, SRC_FILTER = 2, SRC_SIGNED = 3, SRC_TERNARY = 4, SRC_CT_PLAIN = 5 };
 struct NttSource {
   const u64 *p;
   const u64 *p2;                   // inverse transform of a product: the key pair [2][limbs][N] (p = [n][limbs][N])
@@ -226,6 +229,7 @@ struct NttSource {
   int fw, origin, plane, row;      // coefficient = origin - cc*plane - r*row - col
   ChaChaKey key;                   // SRC_TERNARY: the sampler's key, the ternary stream's id and the tile of polynomial 0
   u64 sid, first_tile;
+  const BfvConsts *bfv;            // SRC_CT_PLAIN: the context's BFV constants (device memory)
 };
 
 // The EA = N/256 stride-256 coefficients of thread t, from wherever the transform reads them.
@@ -234,7 +238,22 @@ __device__ __forceinline__ void load_source(u32 unit, u64 (&x)[1 << (LOGN - 8)],
                                             const DevMod &M, const NttSource &src, int limbs, u64 *lds) {
   constexpr int EA = 1 << (LOGN - 8);
   const int t = threadIdx.x;
-  if (SRC == SRC_TERNARY) {
+  if (SRC == SRC_CT_PLAIN) {
+    const u32 poly = unit / limbs, l = unit % limbs;
+    const u64 *__restrict__ c = src.p + ((size_t)unit << LOGN);
+#pragma unroll
+    for (int k = 0; k < EA; ++k) x[k] = c[k * 256 + t];
+    if ((poly & 1) == 0 && src.p2) {   // c0 of ciphertext poly / 2
+      const u64 *__restrict__ m = src.p2 + ((size_t)(poly >> 1) << LOGN);
+      const BfvConsts &b = *src.bfv;
+      const LevelConsts &lc = b.lv[0];
+#pragma unroll
+      for (int k = 0; k < EA; ++k) {
+        const u64 mv = m[k * 256 + t];
+        if (mv) x[k] = add_mod(x[k], scaled_plain(mv, scale_fix(mv, b, lc), lc.delta_mod_q[l], M), M.q);
+      }
+    }
+  } else if (SRC == SRC_TERNARY) {
 #pragma unroll
     for (int h = 0; h < EA / 16; ++h) {
       int64_t v[16];

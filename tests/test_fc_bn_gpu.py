@@ -310,6 +310,60 @@ def test_network_bn_layer_bit_exact(mm, n):
     assert d.min() >= 0 and d.max() <= 2 and int((d == 2).sum()) <= 2
 
 
+@pytest.mark.parametrize("n", [5, 1000, 4096, 3 * 4096 + 77, 7 * 7 * 1024])
+def test_alice_bn_layer_in_two_calls(mm, n):
+    """ALICE's side of a batch-norm layer as mmh_bn_alice_prepare + mmh_bn_alice_finish (seven launches): the three
+    plaintext batches, her share, every byte of the COT's wire and the result ciphertexts against the ORACLE's separate
+    steps (Ring2Field as the COT sender, HomBNSS::encodeVector twice, HomBNSS::bn with addMask) on the same blocks;
+    r's words are the ChaCha20 stream that tests/test_sampler_gpu.py pins against RFC 8439."""
+    import ctypes as C
+    import torch
+    from openmm_amd import lib as L
+    from tests.oracle_binding import A, load
+    ol, lib = load(), L.load_library()
+    bw, p, gid0 = 37, 137438822401, 8 * 77
+    o, g = OracleCtx(N, (60, 49), p), mm.Context(N, (60, 49), p)
+    bn = BnOracle(o, n)
+    u2 = lambda v: (C.c_uint64 * 2)(int(v[0]), int(v[1]))
+    delta = splitmix64(SEED + 80, 2) | np.uint64(1)
+    S, rcm = splitmix64(SEED + 81, 2), splitmix64(SEED + 82, 2 * n)
+    x = splitmix64(SEED + 83, n) & np.uint64((1 << bw) - 1)
+    scale_f = splitmix64(SEED + 84, n) % np.uint64(p)
+    cts = np.stack([rns_uniform(o, SEED + 85, bn.n_ct, 2), rns_uniform(o, SEED + 86, bn.n_ct, 2)], axis=1)
+    key = (C.c_uint32 * 8)(*[int(v) for v in splitmix64(SEED + 87, 8) & np.uint64(0xFFFFFFFF)])
+    sid = 0x1234
+    # the oracle's steps
+    tmp, msb, corr, fld = np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    ol.mmo_r2f_pre(1, A(x), n, bw, p, A(tmp), A(msb), A(corr))
+    nbytes = ol.mmo_cot_wire_bytes(n, 0, p, 1)
+    wire, y = np.zeros(nbytes + 8, np.uint8), np.zeros(n, np.uint64)
+    ol.mmo_cot_send(A(rcm), A(delta), A(S), gid0, A(corr), n, 0, p, 1, A(y), A(wire))
+    ol.mmo_r2f_post(1, A(tmp), A(msb), A(y), n, bw, p, A(fld))
+    d_words = torch.empty(n, dtype=torch.int64, device="cuda")
+    L.check(lib.mmh_chacha20_words(key, sid, 0, L.dptr(d_words), n, None))
+    rnd = host(d_words)
+    ref_in, ref_sc = bn.encode(fld), bn.encode(scale_f)
+    ref_r = bn.encode(rnd % np.uint64(p))
+    ref_out, ref_share = bn.bn(cts, ref_in, ref_sc, rnd)
+    # the two calls
+    d_pts3 = torch.full((3, bn.n_ct, N), -1, dtype=torch.int64, device="cuda")
+    d_share = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+    d_wire = torch.full(((nbytes + 7) // 8 + 1,), -1, dtype=torch.int64, device="cuda")
+    d_rcm, d_x, d_sc, d_cts = dev(rcm), dev(x), dev(scale_f), dev(cts)   # named: a temporary's memory is reused at once
+    L.check(lib.mmh_bn_alice_prepare(g.handle, L.dptr(d_rcm), u2(delta), u2(S), gid0, L.dptr(d_x), n, bw, L.dptr(d_sc), key,
+                                     sid, L.dptr(d_pts3), L.dptr(d_share), L.dptr(d_wire), None))
+    pts3 = host(d_pts3)
+    assert np.array_equal(pts3[0], ref_in) and np.array_equal(pts3[1], ref_sc) and np.array_equal(pts3[2], ref_r)
+    assert np.array_equal(host(d_share), ref_share)
+    gw = d_wire.cpu().numpy().view(np.uint8)
+    assert np.array_equal(gw[:nbytes], wire[:nbytes]) and (gw[nbytes:] == 0xFF).all()
+    d_out = torch.full((bn.n_ct, 2, N), -1, dtype=torch.int64, device="cuda")
+    L.check(lib.mmh_bn_alice_finish(g.handle, L.dptr(d_cts), L.dptr(d_pts3), n, L.dptr(d_out), None))
+    assert np.array_equal(host(d_out), ref_out.reshape(bn.n_ct, 2, N))
+    with pytest.raises(mm.MMHError):
+        L.check(lib.mmh_bn_alice_finish(g.handle, None, L.dptr(d_pts3), n, L.dptr(d_out), None))
+
+
 def test_bole_full_size_identity(mm):
     """bole_test flags 1 1 size: 2^20 elements, l=32, |x|,|y| < 2^12 (tests/bole_test.cpp:78,98,568)"""
     import torch
