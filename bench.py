@@ -25,13 +25,13 @@ MADS_PER_BUTTERFLY = (9 + 8) / 2
 MAD_PEAK = 34.5e12         # lanes/s measured on MI355X (profiles/r01_a_valu_probe.txt, r01_f64_probe.txt)
 
 
-PMC_FILE = "profiles/r02_ntt_pmc.json"
+PMC_FILE = "profiles/r03_ntt_pmc.json"
 
 
 def pmc_traffic(ntts_per_launch):
     """HBM bytes per launch of ntt_fwd_kernel<12>: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of
     MI355X_MICROARCH.md) from separate rocprofv3 --pmc passes over the same kernel (tools/evidence.sh ->
-    profiles/r02_ntt_pmc.json, collected on 8192 limb-NTTs per launch), scaled to this launch: the RECORDED figure,
+    profiles/r03_ntt_pmc.json, collected on 8192 limb-NTTs per launch), scaled to this launch: the RECORDED figure,
     used when measured_traffic() below cannot run; `traffic_source` in the line says which of the two it is."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
@@ -601,7 +601,7 @@ def resnet50_leg(torch, dist, openmm_amd, local, world, rank, reps=20, convs=Non
         work["direct_layers"] += count * int(wk["direct"])
         work["layers"] += count
 
-        def layer():   # encodeImage + encodeFilters + conv2DSS in one device call, its randomness drawn first
+        def layer():   # encodeImage + encodeFilters + conv2DSS in one device call that draws its randomness too
             return srv.conv2DSSFromTensors(cts, share, filters, meta, net.sampler, defer_verdict=True)
 
         if world == 1 and not prepared:

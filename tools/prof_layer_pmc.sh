@@ -22,7 +22,7 @@ for G in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 done
 {
   echo "# layer: $L"; cat $O/plain.log; echo "# kernel times (rocprofv3 --kernel-trace --stats)"; cat $O/kernels.csv
-  for K in pw_mfma_kernel ntt_inv_kernel pw_expand_kernel conv_front_kernel reshare_elem_kernel; do
+  for K in pw_mfma_kernel pw_narrow_kernel ntt_inv_kernel pw_expand_kernel conv_front_kernel reshare_elem_kernel; do
     echo "## $K"; python3 tools/pmc_summary.py $K $O/p1 $O/p2 $O/p3 $O/p4
   done
 } > $O/pmc.txt

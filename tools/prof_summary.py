@@ -10,7 +10,8 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
 print("kernel,calls,total_us,avg_us,percent")
 for name, calls, total, avg, pct in rows[:top]:
-    short = re.sub(r"\(.*", "", name)            # drop the argument list
+    short = name.replace("(anonymous namespace)::", "")
+    short = re.sub(r"\(.*", "", short)           # drop the argument list
     short = re.sub(r"^void ", "", short)
     if len(short) > 90:
         short = short[:87] + "..."
