@@ -501,21 +501,19 @@ class NetworkLegs:
 
         def call():
             s = L._stream_ptr()
-            # what needs no ciphertext (four launches): Ring2Field with ALICE as the COT sender (truncation.cpp:518-581;
-            # silent_ot.h:129-163) into encodeVector's plaintexts, the scales' plaintexts, addMask's r drawn in place
+            # what needs no ciphertext, two launches: Ring2Field with ALICE as the COT sender (truncation.cpp:518-581;
+            # silent_ot.h:129-163) into encodeVector's plaintexts, the scales' plaintexts, addMask's r drawn in place and
+            # Field2Ring_with_Truncate on her share -r (truncation.cpp:639-695; silent_ot.h:85-127), side by side; then
+            # BatchEncoder's transform of the three plaintext batches
             pts3 = torch.empty(3, n_ct, N, dtype=torch.int64, device="cuda")
-            share, out = (torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(2))
+            out = torch.empty(n, dtype=torch.int64, device="cuda")
             out_cts = torch.empty(n_ct, 2, N, dtype=torch.int64, device="cuda")
-            L.check(lib.mmh_bn_alice_prepare(h, L.dptr(rcm[0]), delta, seed, self.gid, L.dptr(x), n, l, L.dptr(scale),
-                                             self.sampler.key, self.sampler._sid(), L.dptr(pts3), L.dptr(share),
-                                             L.dptr(wires[0]), s))
-            self.gid += gids.value
+            L.check(lib.mmh_bn_alice_prepare(h, L.dptr(rcm[0]), L.dptr(rcm[1]), delta, seed, seed, self.gid, L.dptr(x), n, l,
+                                             K_SCALE, L.dptr(scale), self.sampler.key, self.sampler._sid(), L.dptr(pts3),
+                                             None, L.dptr(out), L.dptr(wires[0]), L.dptr(wires[1]), s))
+            self.gid += 2 * gids.value
             # HomBNSS::bn on the client's ciphertexts (three launches)
             L.check(lib.mmh_bn_alice_finish(h, L.dptr(cts), L.dptr(pts3), n, L.dptr(out_cts), s))
-            # Field2Ring_with_Truncate on her share (truncation.cpp:639-695; silent_ot.h:85-127), one launch
-            L.check(lib.mmh_cot_send_f2r(L.dptr(rcm[1]), delta, seed, self.gid, L.dptr(share), n, p, l, K_SCALE,
-                                         L.dptr(out), L.dptr(wires[1]), s))
-            self.gid += gids.value
             return out_cts, out
         return call
 

@@ -674,21 +674,29 @@ int mmh_cot_send_r2f_encode(const mmh_ctx *ctx, const uint64_t *d_rcm, const uin
                             void *stream);
 /* ALICE's (the model owner's) side of one batch-norm layer, ElemWiseActModelVectorMult around CheetahLinear::bn
  * (library_fixed_uniform_cheetah.cpp:567-600, cheetah-api.cpp:621-660, hom_bn_ss.cc:236-276 and :333-357), as two calls
- * that meet at the client's ciphertexts, with the launches of the step-by-step entry points merged:
- *   mmh_bn_alice_prepare  everything that does not need the client's ciphertexts: mmh_cot_send_r2f_encode of her ring
- *                         share d_x (n elements, bw bits), HomBNSS::encodeVector of the scales d_scales (n field
- *                         elements), and addMask's r drawn on the device -- element e gets word e of
- *                         mmh_chacha20_words(key, stream_id, 0, ...), r = word mod p, d_out_share[e] = -r mod p.
- *                         d_pts3 [3][n_ct][N] receives the three plaintext batches (her share, the scales, r), n_ct =
- *                         ceil(n / min(n, N)); d_wire as for mmh_cot_send_r2f_encode.  Four launches.
+ * that meet at the client's ciphertexts, with the launches of the step-by-step entry points merged (13 -> 5):
+ *   mmh_bn_alice_prepare  everything that does not need the client's ciphertexts, two launches.  The first runs side by
+ *                         side: Ring2Field of her ring share d_x (n elements, bw bits) as the COT sender into
+ *                         encodeVector's plaintexts (= mmh_cot_send_r2f_encode: blocks d_rcm_r2f, seed_r2f, key counter
+ *                         gid0, wire d_wire_r2f); HomBNSS::encodeVector of the scales d_scales (n field elements);
+ *                         addMask's r drawn on the device -- element e gets word e of mmh_chacha20_words(key,
+ *                         stream_id, 0, ...), r = word mod p, her share -r mod p (stored to d_out_share unless null) --
+ *                         and, on that share, Field2Ring (shift < 0) or Field2Ring_with_Truncate as the COT sender
+ *                         (= mmh_cot_send_f2r: blocks d_rcm_f2r, seed_f2r, key counter gid0 + mmh_cot_gids(n), wire
+ *                         d_wire_f2r, her ring share of the layer's result in d_out_ring): her share does not depend on
+ *                         the ciphertexts, so neither does its conversion.  The second is BatchEncoder's inverse
+ *                         transform of the three plaintext batches d_pts3 [3][n_ct][N] (her share, the scales, r), n_ct =
+ *                         ceil(n / min(n, N)).  A call advances the key counter by 2 * mmh_cot_gids(n).
  *   mmh_bn_alice_finish   add_plain, multiply_plain by the scales, mod-switch to the last level, add_plain of r and
  *                         truncate_for_decryption on the client's ciphertexts d_in_cts [n_ct][2][2][N] into d_out_cts
  *                         [n_ct][2][N].  Three launches.
- * Bit for bit mmh_cot_send_r2f_encode + mmh_bn_encode_vector + mmh_chacha20_words + mmh_bn_server; two moduli only. */
-int mmh_bn_alice_prepare(const mmh_ctx *ctx, const uint64_t *d_rcm, const uint64_t delta[2], const uint64_t seed[2],
-                         uint64_t gid0, const uint64_t *d_x, size_t n, int bw, const uint64_t *d_scales,
+ * Bit for bit mmh_cot_send_r2f_encode + mmh_bn_encode_vector + mmh_chacha20_words + mmh_bn_server + mmh_cot_send_f2r,
+ * wire bytes included; two moduli only. */
+int mmh_bn_alice_prepare(const mmh_ctx *ctx, const uint64_t *d_rcm_r2f, const uint64_t *d_rcm_f2r,
+                         const uint64_t delta[2], const uint64_t seed_r2f[2], const uint64_t seed_f2r[2], uint64_t gid0,
+                         const uint64_t *d_x, size_t n, int bw, int shift, const uint64_t *d_scales,
                          const uint32_t key[8], uint64_t stream_id, uint64_t *d_pts3, uint64_t *d_out_share,
-                         uint8_t *d_wire, void *stream);
+                         uint64_t *d_out_ring, uint8_t *d_wire_r2f, uint8_t *d_wire_f2r, void *stream);
 int mmh_bn_alice_finish(const mmh_ctx *ctx, const uint64_t *d_in_cts, const uint64_t *d_pts3, size_t n,
                         uint64_t *d_out_cts, void *stream);
 

@@ -15,6 +15,7 @@
 
 #include "common.hpp"
 #include "convert_device.hpp"
+#include "sampler_device.hpp"
 
 namespace mmh {
 namespace {
@@ -152,7 +153,11 @@ __device__ __forceinline__ u64 words64(u32 lo, u32 hi) { return make64(lo, hi); 
 //   CONV_R2F_ENCODE  ring_to_field (:518-581) whose field elements go straight into BatchEncoder's slot order for
 //                    HomBNSS::encodeVector (hom_bn_ss.cc:203-233; the inverse transform follows): out = pts [n_ct][N]
 //   CONV_F2R         field_to_ring (:583-637) or, truncating, field_to_ring_with_truncate (:639-695): out = [n]
-enum { CONV_NONE = 0, CONV_R2F_ENCODE = 1, CONV_F2R = 2 };
+//   CONV_F2R_DRAW    CONV_F2R on the share -r of HomBNSS::addMask (hom_bn_ss.cc:333-340), r DRAWN here: element e takes
+//                    word e of the ChaCha20 stream (key, sid) -- the first 64 lanes of a workgroup compute the 64 blocks
+//                    its 512 elements need and hand them over through `stage` -- r = word mod p also goes into
+//                    BatchEncoder's slot order (pts_r) and, if asked for, -r into share_out
+enum { CONV_NONE = 0, CONV_R2F_ENCODE = 1, CONV_F2R = 2, CONV_F2R_DRAW = 3 };
 struct CotConv {
   const u64 *in;
   u64 *out;
@@ -162,26 +167,59 @@ struct CotConv {
   size_t sub_len;
   int logN;
   ModC t;
+  ChaChaKey key;             // CONV_F2R_DRAW
+  u64 sid;
+  u64 *pts_r, *share_out;
+};
+struct CotSendArgs {
+  const uint4 *rcm;
+  uint4 delta, S;
+  u64 gid0;
+  const u64 *corr;
+  size_t n;
+  int l;
+  PrimeMod pm;
+  u64 *data0;
+  uint8_t *wire;
+  CotConv cv;
 };
 // Sender.  rcm [n] blocks; element j is hashed under key S ^ (gid0 + j in the high half).
 // Ring: wire holds, per group of 8 elements, ceil(8*l/64) words (a ragged last group ceil(rem*l/64)).
 // Prime: wire holds `bytes` bytes per element, back to back.
-template <bool PRIME, int CONV = CONV_NONE>
-__global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__restrict__ rcm, uint4 delta, uint4 S,
-                                                                u64 gid0, const u64 *__restrict__ corr, size_t n,
-                                                                int l, PrimeMod pm, u64 *__restrict__ data0,
-                                                                uint8_t *__restrict__ wire, CotConv cv = CotConv{}) {
-  __shared__ u32 table[256 * kCopies];
-  __shared__ u64 stage[kCotThreads];
-  fill_table(table);
+// The sender's work of workgroup `block` of `nblocks` (a kernel of its own below, a range of workgroups in
+// bn_alice_front_kernel); `table` is filled, `stage` holds kCotThreads words.
+template <bool PRIME, int CONV>
+__device__ __forceinline__ void cot_send_body(const CotSendArgs &a, unsigned block, unsigned nblocks, const u32 *table,
+                                              u64 *stage) {
+  const uint4 *__restrict__ rcm = a.rcm;
+  const uint4 delta = a.delta, S = a.S;
+  const u64 gid0 = a.gid0;
+  const u64 *__restrict__ corr = a.corr;
+  const size_t n = a.n;
+  const int l = a.l;
+  const PrimeMod &pm = a.pm;
+  u64 *__restrict__ data0 = a.data0;
+  uint8_t *__restrict__ wire = a.wire;
+  const CotConv &cv = a.cv;
   const Aes aes{table + (threadIdx.x & (kCopies - 1))};
   const u64 mask = l >= 64 ? ~u64(0) : (u64(1) << l) - 1;
   const int wpg = (kBatch * l + 63) / 64;  // words per full group
   const size_t n_chunks = (n + kCotThreads - 1) / kCotThreads;
-  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (size_t chunk = block; chunk < n_chunks; chunk += nblocks) {
     const size_t base = chunk * kCotThreads, j = base + threadIdx.x;
     const int live = (int)min((size_t)kCotThreads, n - base);
     u64 cd = 0;
+    if (CONV == CONV_F2R_DRAW) {
+      __syncthreads();  // the previous chunk's packing is done with stage
+      const size_t blk = base / 8 + threadIdx.x;   // (base is a multiple of 8: word e of the stream is element e's)
+      if (threadIdx.x < kCotThreads / 8 && blk * 8 < n) {
+        u64 w[8];
+        chacha20_block(cv.key, cv.sid, blk, w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stage[threadIdx.x * 8 + k] = w[k];
+      }
+      __syncthreads();
+    }
     if (j < n) {
       const uint4 r = rcm[j];
       const u64 gid = gid0 + j;
@@ -196,6 +234,14 @@ __global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__re
         c = m ? 0 : cv.cv;
       } else if (CONV == CONV_F2R) {   // :601-607 / :657-665 (ALICE)
         tmpv = f2r_pre_elem(kAlice, cv.in[j], cv.p, m);
+        c = m ? 0 : cv.cv;
+      } else if (CONV == CONV_F2R_DRAW) {   // hom_bn_ss.cc:333-340, then as CONV_F2R on the share
+        const u64 r = barrett128(0, stage[threadIdx.x], cv.t.q, cv.t.barrett_hi, cv.t.barrett_lo);
+        const u64 share = r ? cv.p - r : 0;
+        const size_t k = j / cv.sub_len, i = j - k * cv.sub_len;
+        cv.pts_r[(k << cv.logN) + cv.map[i]] = r;
+        if (cv.share_out) cv.share_out[j] = share;
+        tmpv = f2r_pre_elem(kAlice, share, cv.p, m);
         c = m ? 0 : cv.cv;
       } else {
         c = corr[j];
@@ -216,7 +262,7 @@ __global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__re
         cd = mod128(hi, lo, pm);
       } else {  // silent_ot.h:112-115
         const u64 d0 = words64(blk[0][0], blk[0][1]) & mask;
-        if (CONV == CONV_F2R) {   // truncation.cpp:609-611, :626-634 / :667-669, :684-692 (ALICE); mask = 2^bw - 1 = 2^l - 1
+        if (CONV == CONV_F2R || CONV == CONV_F2R_DRAW) {   // truncation.cpp:609-611, :626-634 / :667-669, :684-692 (ALICE); mask = 2^bw - 1 = 2^l - 1
           const u64 yy = m ? ((cv.cv - d0) & mask) : ((0 - d0) & mask), big = cv.p / 4;
           const u64 o = cv.truncating ? ((tmpv - big) >> cv.shift) - yy : tmpv - yy - big;
           cv.out[j] = o & mask;
@@ -269,6 +315,52 @@ __global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__re
       }
     }
   }
+}
+
+template <bool PRIME, int CONV = CONV_NONE>
+__global__ __launch_bounds__(kCotThreads) void cot_send_kernel(const uint4 *__restrict__ rcm, uint4 delta, uint4 S,
+                                                                u64 gid0, const u64 *__restrict__ corr, size_t n,
+                                                                int l, PrimeMod pm, u64 *__restrict__ data0,
+                                                                uint8_t *__restrict__ wire, CotConv cv = CotConv{}) {
+  __shared__ u32 table[256 * kCopies];
+  __shared__ u64 stage[kCotThreads];
+  fill_table(table);
+  const CotSendArgs a{rcm, delta, S, gid0, corr, n, l, pm, data0, wire, cv};
+  cot_send_body<PRIME, CONV>(a, blockIdx.x, gridDim.x, table, stage);
+}
+
+// ALICE's work on a batch-norm layer that needs no ciphertext, as ONE launch (mmh_bn_alice_prepare, fc_bn.hip): workgroups
+// [0, nb_a) are the sender of ring_to_field feeding encodeVector (CONV_R2F_ENCODE), the next nb_b the sender of
+// field_to_ring[_with_truncate] on the share -r they draw (CONV_F2R_DRAW), the rest chunk-scatter the model's scales
+// into BatchEncoder's slot order (encodeVector, hom_bn_ss.cc:203-233) and write the zeros of the three batches' slots
+// past the vector's end.  The three are independent and each alone is too small to fill the chip.
+struct BnScalesArgs {
+  const u64 *scales;
+  u64 *pts_in, *pts_scales, *pts_r;
+  size_t n_ct, n, sub_len;
+  int logN;
+  const u32 *map;
+  ModC t;
+};
+__global__ __launch_bounds__(kCotThreads) void bn_alice_front_kernel(CotSendArgs a, CotSendArgs b, unsigned nb_a,
+                                                                      unsigned nb_b, BnScalesArgs sc) {
+  __shared__ u32 table[256 * kCopies];
+  __shared__ u64 stage[kCotThreads];
+  if (blockIdx.x >= nb_a + nb_b) {
+    const size_t idx = (size_t)(blockIdx.x - nb_a - nb_b) * kCotThreads + threadIdx.x;
+    if (idx >= (sc.n_ct << sc.logN)) return;
+    const size_t k = idx >> sc.logN, i = idx & ((size_t(1) << sc.logN) - 1), src = k * sc.sub_len + i;
+    const size_t slot = (k << sc.logN) + sc.map[i];
+    if (i < sc.sub_len && src < sc.n) {
+      sc.pts_scales[slot] = barrett128(0, sc.scales[src], sc.t.q, sc.t.barrett_hi, sc.t.barrett_lo);
+    } else {
+      sc.pts_scales[slot] = 0, sc.pts_in[slot] = 0, sc.pts_r[slot] = 0;
+    }
+    return;
+  }
+  fill_table(table);
+  if (blockIdx.x < nb_a) cot_send_body<true, CONV_R2F_ENCODE>(a, blockIdx.x, nb_a, table, stage);
+  else cot_send_body<false, CONV_F2R_DRAW>(b, blockIdx.x - nb_a, nb_b, table, stage);
 }
 
 // Receiver.  rcm [n] blocks (its own), b [n] choice bits as bytes.
@@ -351,6 +443,32 @@ int cot_send_r2f_encode_launch(const u64 *d_rcm, const uint64_t delta[2], const 
   hipLaunchKernelGGL((cot_send_kernel<true, CONV_R2F_ENCODE>), dim3(cot_grid(n)), dim3(kCotThreads), 0, s,
                      (const uint4 *)d_rcm, as_block(delta), as_block(seed), gid0, (const u64 *)nullptr, n, 64, make_prime(p),
                      (u64 *)nullptr, d_wire, cv);
+  MMH_HIP(hipGetLastError());
+  return MMH_OK;
+}
+// mmh_bn_alice_prepare's one launch (see bn_alice_front_kernel); gid0 is the first conversion's, the second follows it
+int bn_alice_front_launch(const u64 *d_rcm_r2f, const u64 *d_rcm_f2r, const uint64_t delta[2], const uint64_t seed_r2f[2],
+                          const uint64_t seed_f2r[2], u64 gid0, const u64 *d_x, size_t n, int bw, int shift, u64 p,
+                          const u64 *d_scales, const uint32_t key[8], u64 sid, u64 *d_pts3, size_t n_ct, const u32 *d_map,
+                          size_t sub_len, int logN, const ModC &t, u64 *d_share, u64 *d_out_ring, uint8_t *d_wire_r2f,
+                          uint8_t *d_wire_f2r, hipStream_t s) {
+  const u64 mask = bw >= 64 ? ~u64(0) : (u64(1) << bw) - 1;
+  const size_t N = size_t(1) << logN;
+  u64 *pts_in = d_pts3, *pts_sc = d_pts3 + n_ct * N, *pts_r = d_pts3 + 2 * n_ct * N;
+  CotSendArgs a{}, b{};
+  a.rcm = (const uint4 *)d_rcm_r2f, a.delta = as_block(delta), a.S = as_block(seed_r2f), a.gid0 = gid0, a.n = n, a.l = 64;
+  a.pm = make_prime(p), a.wire = d_wire_r2f;
+  a.cv.in = d_x, a.cv.out = pts_in, a.cv.p = p, a.cv.cv = mask % p + 1, a.cv.big_mod_p = (u64(1) << (bw - 2)) % p;
+  a.cv.bw = bw, a.cv.map = d_map, a.cv.sub_len = sub_len, a.cv.logN = logN, a.cv.t = t;
+  b.rcm = (const uint4 *)d_rcm_f2r, b.delta = a.delta, b.S = as_block(seed_f2r);
+  b.gid0 = gid0 + kBatch * (u64)((n + kBatch - 1) / kBatch), b.n = n, b.l = bw, b.pm = make_prime(2), b.wire = d_wire_f2r;
+  b.cv.out = d_out_ring, b.cv.p = p, b.cv.truncating = shift >= 0, b.cv.shift = shift >= 0 ? shift : 0;
+  b.cv.cv = shift >= 0 ? p >> shift : p, b.cv.bw = bw, b.cv.map = d_map, b.cv.sub_len = sub_len, b.cv.logN = logN, b.cv.t = t;
+  for (int i = 0; i < 8; ++i) b.cv.key.k[i] = key[i];
+  b.cv.sid = sid, b.cv.pts_r = pts_r, b.cv.share_out = d_share;
+  const BnScalesArgs sc{d_scales, pts_in, pts_sc, pts_r, n_ct, n, sub_len, logN, d_map, t};
+  const unsigned nb = cot_grid(n), nb_sc = (unsigned)(((n_ct << logN) + kCotThreads - 1) / kCotThreads);
+  hipLaunchKernelGGL(bn_alice_front_kernel, dim3(nb + nb + nb_sc), dim3(kCotThreads), 0, s, a, b, nb, nb, sc);
   MMH_HIP(hipGetLastError());
   return MMH_OK;
 }

@@ -5,7 +5,6 @@
 #include "common.hpp"
 #include "convert_device.hpp"
 #include "geometry.hpp"
-#include "sampler_device.hpp"
 
 namespace mmh {
 int reshare_tail_approx(const mmh_ctx *ctx, u64 *d_acc, bool acc_ntt_form, size_t n, const u64 *d_pk_ntt_last,
@@ -17,6 +16,11 @@ int ntt_inv_product_each_dispatch(const mmh_ctx *ctx, const u64 *d_pt_ntt, const
                                   const u64 *d_ct2_ntt, u64 *d_out, size_t n, int limbs, hipStream_t s);
 int ntt_bn_front_dispatch(const mmh_ctx *ctx, const u64 *d_cts, const u64 *d_share_pts, const u64 *d_scale_pts, size_t n,
                           u64 *d_sum, u64 *d_pt_ntt, hipStream_t s);
+int bn_alice_front_launch(const u64 *d_rcm_r2f, const u64 *d_rcm_f2r, const uint64_t delta[2], const uint64_t seed_r2f[2],
+                          const uint64_t seed_f2r[2], u64 gid0, const u64 *d_x, size_t n, int bw, int shift, u64 p,
+                          const u64 *d_scales, const uint32_t key[8], u64 sid, u64 *d_pts3, size_t n_ct, const u32 *d_map,
+                          size_t sub_len, int logN, const ModC &t, u64 *d_share, u64 *d_out_ring, uint8_t *d_wire_r2f,
+                          uint8_t *d_wire_f2r, hipStream_t s);
 int cot_send_r2f_encode_launch(const u64 *d_rcm, const uint64_t delta[2], const uint64_t seed[2], u64 gid0, const u64 *d_x,
                                size_t n, int bw, u64 p, u64 *d_pts, const u32 *d_map, size_t sub_len, int logN,
                                const ModC &t, uint8_t *d_wire, hipStream_t s);
@@ -156,43 +160,6 @@ __global__ __launch_bounds__(256) void bn_mask_scatter_kernel(const u64 *__restr
     share[src] = v ? t.q - v : 0;
   }
   pts[(k << logN) + map[i]] = v;
-}
-// The model's scales and addMask's r for mmh_bn_alice_prepare in one pass.  Blocks [0, nb_scales) are
-// chunk_scatter_kernel on the scales; the others draw r where it is used: lane g of them takes ChaCha20 block g of
-// stream `sid` (words 8g .. 8g+7 of mmh_chacha20_words(key, sid, 0, ...), so element e of the vector gets word e, as
-// when the caller draws n words and hands them to mmh_bn_server), r = word mod p into BatchEncoder's slot order,
-// share = -r mod p.
-__global__ __launch_bounds__(256) void bn_scales_mask_kernel(const u64 *__restrict__ scales, u64 *__restrict__ pts_scales,
-                                                             u64 *__restrict__ pts_r, u64 *__restrict__ share,
-                                                             ChaChaKey key, u64 sid, unsigned nb_scales, size_t n_ct,
-                                                             size_t n, size_t sub_len, int logN,
-                                                             const u32 *__restrict__ map, ModC t) {
-  const size_t Nm = (size_t(1) << logN) - 1;
-  if (blockIdx.x < nb_scales) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (n_ct << logN)) return;
-    const size_t k = idx >> logN, i = idx & Nm;
-    const size_t src = k * sub_len + i;
-    const u64 v = (i < sub_len && src < n) ? scales[src] : 0;
-    pts_scales[(k << logN) + map[i]] = red_t2(v, t);
-    return;
-  }
-  const size_t g = (size_t)(blockIdx.x - nb_scales) * 256 + threadIdx.x;   // slots 8g .. 8g+7
-  if (g * 8 >= (n_ct << logN)) return;
-  const size_t k = (g * 8) >> logN, i0 = (g * 8) & Nm;
-  u64 w[8];
-  const bool any = i0 < sub_len && k * sub_len + i0 < n;   // wave-uniform except at the vector's end
-  if (any) chacha20_block(key, sid, g, w);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const size_t i = i0 + j, src = k * sub_len + i;
-    u64 v = 0;
-    if (any && i < sub_len && src < n) {
-      v = red_t2(w[j], t);
-      share[src] = v ? t.q - v : 0;
-    }
-    pts_r[(k << logN) + map[i]] = v;
-  }
 }
 // The rest of bn / bole per coefficient: mod_switch_to_inplace(last) of the product (hom_bn_ss.cc:269,:308), addMask's
 // add_plain_inplace of encode(r) at the last level (:355) and truncate_for_decryption (:357), one pass.
@@ -542,31 +509,23 @@ extern "C" int mmh_bn_server(const mmh_ctx *ctx, const uint64_t *d_in_cts, const
 }
 
 // ALICE's side of a batch-norm layer in two calls that meet at the client's ciphertexts (see include/mm_hip.h)
-extern "C" int mmh_bn_alice_prepare(const mmh_ctx *ctx, const uint64_t *d_rcm, const uint64_t delta[2],
-                                    const uint64_t seed[2], uint64_t gid0, const uint64_t *d_x, size_t n, int bw,
+extern "C" int mmh_bn_alice_prepare(const mmh_ctx *ctx, const uint64_t *d_rcm_r2f, const uint64_t *d_rcm_f2r,
+                                    const uint64_t delta[2], const uint64_t seed_r2f[2], const uint64_t seed_f2r[2],
+                                    uint64_t gid0, const uint64_t *d_x, size_t n, int bw, int shift,
                                     const uint64_t *d_scales, const uint32_t key[8], uint64_t stream_id,
-                                    uint64_t *d_pts3, uint64_t *d_out_share, uint8_t *d_wire, void *stream) {
+                                    uint64_t *d_pts3, uint64_t *d_out_share, uint64_t *d_out_ring, uint8_t *d_wire_r2f,
+                                    uint8_t *d_wire_f2r, void *stream) {
   MMH_DEVICE_SCOPE(ctx);
   size_t sub, n_ct;
   CHECK_RC(bn_counts(ctx, n, &sub, &n_ct));
-  MMH_REQUIRE(d_rcm && delta && seed && d_x && d_scales && key && d_pts3 && d_out_share && d_wire, MMH_ERR_NULL_POINTER);
-  MMH_REQUIRE(bw >= 2 && bw <= 64 && n <= ((size_t)1 << 40), MMH_ERR_INVALID_ARG);
+  MMH_REQUIRE(d_rcm_r2f && d_rcm_f2r && delta && seed_r2f && seed_f2r && d_x && d_scales && key && d_pts3 && d_out_ring &&
+                  d_wire_r2f && d_wire_f2r,
+              MMH_ERR_NULL_POINTER);
+  MMH_REQUIRE(bw >= 2 && bw <= 64 && shift < 64 && ctx->t >= 4 && n <= ((size_t)1 << 40), MMH_ERR_INVALID_ARG);
   hipStream_t s = (hipStream_t)stream;
-  const size_t N = ctx->N;
-  // when n < N the chunk is the whole vector and word e of the stream is element e; when n >= N chunks are N long and
-  // slot k N + i is element k N + i: either way ChaCha block g covers elements 8g .. 8g+7, which needs 8 | sub
-  // or a single chunk
-  MMH_REQUIRE(n_ct == 1 || sub % 8 == 0, MMH_ERR_INVALID_ARG);
-  u64 *pts_in = d_pts3, *pts_sc = d_pts3 + n_ct * N, *pts_r = d_pts3 + 2 * n_ct * N;
-  if (n != n_ct * N) MMH_HIP(hipMemsetAsync(pts_in + (n_ct - 1) * N, 0, N * 8, s));
-  CHECK_RC(cot_send_r2f_encode_launch(d_rcm, delta, seed, gid0, d_x, n, bw, ctx->t, pts_in, ctx->d_slot_map, sub, ctx->logN,
-                                      ctx->bfv.t, d_wire, s));
-  ChaChaKey k;
-  for (int i = 0; i < 8; ++i) k.k[i] = key[i];
-  const unsigned nb_sc = nblk(n_ct << ctx->logN), nb_r = nblk((n_ct << ctx->logN) / 8);
-  hipLaunchKernelGGL(bn_scales_mask_kernel, dim3(nb_sc + nb_r), dim3(256), 0, s, d_scales, pts_sc, pts_r, d_out_share, k,
-                     stream_id, nb_sc, n_ct, n, sub, ctx->logN, ctx->d_slot_map, ctx->bfv.t);
-  MMH_HIP(hipGetLastError());
+  CHECK_RC(bn_alice_front_launch(d_rcm_r2f, d_rcm_f2r, delta, seed_r2f, seed_f2r, gid0, d_x, n, bw, shift, ctx->t, d_scales,
+                                 key, stream_id, d_pts3, n_ct, ctx->d_slot_map, sub, ctx->logN, ctx->bfv.t, d_out_share,
+                                 d_out_ring, d_wire_r2f, d_wire_f2r, s));
   return ntt_dispatch(ctx, true, d_pts3, 3 * n_ct, 1, (int)ctx->L, s);   // BatchEncoder::encode's inverse transform, all three
 }
 

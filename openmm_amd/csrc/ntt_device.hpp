@@ -247,11 +247,12 @@ __device__ __forceinline__ void load_source(u32 unit, u64 (&x)[1 << (LOGN - 8)],
       const u64 *__restrict__ m = src.p2 + ((size_t)(poly >> 1) << LOGN);
       const BfvConsts &b = *src.bfv;
       const LevelConsts &lc = b.lv[0];
+      u64 mv[EA];   // all loads first: a load behind a branch on the previous one's value is not hoisted over it
 #pragma unroll
-      for (int k = 0; k < EA; ++k) {
-        const u64 mv = m[k * 256 + t];
-        if (mv) x[k] = add_mod(x[k], scaled_plain(mv, scale_fix(mv, b, lc), lc.delta_mod_q[l], M), M.q);
-      }
+      for (int k = 0; k < EA; ++k) mv[k] = m[k * 256 + t];
+#pragma unroll
+      for (int k = 0; k < EA; ++k)
+        if (mv[k]) x[k] = add_mod(x[k], scaled_plain(mv[k], scale_fix(mv[k], b, lc), lc.delta_mod_q[l], M), M.q);
     }
   } else if (SRC == SRC_TERNARY) {
 #pragma unroll

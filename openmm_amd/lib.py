@@ -166,8 +166,8 @@ SIGNATURES = {
     "mmh_cot_send_f2r": [_vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _u64, _int, _int, _vp, _vp, _vp],
     "mmh_cot_send_r2f_encode": [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _int, _vp, _vp, _vp],
     "mmh_cot_recv": [_vp, _vp, C.POINTER(_u64), _u64, _vp, _sz, _int, _u64, _int, _vp, _vp],
-    "mmh_bn_alice_prepare": [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _int, _vp, C.POINTER(C.c_uint32),
-                             _u64, _vp, _vp, _vp, _vp],
+    "mmh_bn_alice_prepare": [_vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _u64, _vp, _sz, _int, _int,
+                             _vp, C.POINTER(C.c_uint32), _u64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mmh_bn_alice_finish": [_vp, _vp, _vp, _sz, _vp, _vp],
 }
 

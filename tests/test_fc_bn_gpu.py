@@ -312,9 +312,10 @@ def test_network_bn_layer_bit_exact(mm, n):
 
 @pytest.mark.parametrize("n", [5, 1000, 4096, 3 * 4096 + 77, 7 * 7 * 1024])
 def test_alice_bn_layer_in_two_calls(mm, n):
-    """ALICE's side of a batch-norm layer as mmh_bn_alice_prepare + mmh_bn_alice_finish (seven launches): the three
-    plaintext batches, her share, every byte of the COT's wire and the result ciphertexts against the ORACLE's separate
-    steps (Ring2Field as the COT sender, HomBNSS::encodeVector twice, HomBNSS::bn with addMask) on the same blocks;
+    """ALICE's side of a batch-norm layer as mmh_bn_alice_prepare + mmh_bn_alice_finish (five launches): the three
+    plaintext batches, her share, her ring share of the result, every byte of both COTs' wires and the result
+    ciphertexts against the ORACLE's separate steps (Ring2Field as the COT sender, HomBNSS::encodeVector twice,
+    HomBNSS::bn with addMask, Field2Ring[_with_Truncate] as the COT sender) on the same blocks;
     r's words are the ChaCha20 stream that tests/test_sampler_gpu.py pins against RFC 8439."""
     import ctypes as C
     import torch
@@ -345,18 +346,41 @@ def test_alice_bn_layer_in_two_calls(mm, n):
     ref_in, ref_sc = bn.encode(fld), bn.encode(scale_f)
     ref_r = bn.encode(rnd % np.uint64(p))
     ref_out, ref_share = bn.bn(cts, ref_in, ref_sc, rnd)
+    k = 12
+    S2, rcm2 = splitmix64(SEED + 88, 2), splitmix64(SEED + 89, 2 * n)
+    gid1 = gid0 + 8 * ((n + 7) // 8)
+    ref_ring, ref_wire2 = {}, {}
+    for shift in (k, -1):   # Field2Ring_with_Truncate / Field2Ring on her share, as the sender of the second COT
+        ol.mmo_f2r_pre(1, A(ref_share), n, p, max(shift, 0), A(tmp), A(msb), A(corr))
+        nb2 = ol.mmo_cot_wire_bytes(n, bw, p, 0)
+        w2, y2, o2 = np.zeros(nb2 + 8, np.uint8), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        ol.mmo_cot_send(A(rcm2), A(delta), A(S2), gid1, A(corr), n, bw, p, 0, A(y2), A(w2))
+        if shift < 0:
+            ol.mmo_f2r_post(1, A(tmp), A(msb), A(y2), n, p, bw, A(o2))
+        else:
+            ol.mmo_f2r_trunc_post(1, A(tmp), A(msb), A(y2), n, p, bw, shift, A(o2))
+        ref_ring[shift], ref_wire2[shift] = o2, w2[:nb2]
     # the two calls
-    d_pts3 = torch.full((3, bn.n_ct, N), -1, dtype=torch.int64, device="cuda")
-    d_share = torch.full((n,), -1, dtype=torch.int64, device="cuda")
-    d_wire = torch.full(((nbytes + 7) // 8 + 1,), -1, dtype=torch.int64, device="cuda")
-    d_rcm, d_x, d_sc, d_cts = dev(rcm), dev(x), dev(scale_f), dev(cts)   # named: a temporary's memory is reused at once
-    L.check(lib.mmh_bn_alice_prepare(g.handle, L.dptr(d_rcm), u2(delta), u2(S), gid0, L.dptr(d_x), n, bw, L.dptr(d_sc), key,
-                                     sid, L.dptr(d_pts3), L.dptr(d_share), L.dptr(d_wire), None))
-    pts3 = host(d_pts3)
-    assert np.array_equal(pts3[0], ref_in) and np.array_equal(pts3[1], ref_sc) and np.array_equal(pts3[2], ref_r)
-    assert np.array_equal(host(d_share), ref_share)
-    gw = d_wire.cpu().numpy().view(np.uint8)
-    assert np.array_equal(gw[:nbytes], wire[:nbytes]) and (gw[nbytes:] == 0xFF).all()
+    d_rcm, d_rcm2, d_x, d_sc, d_cts = dev(rcm), dev(rcm2), dev(x), dev(scale_f), dev(cts)   # named: a temporary's memory is reused at once
+    for shift, want_share in ((k, True), (-1, False)):
+        d_pts3 = torch.full((3, bn.n_ct, N), -1, dtype=torch.int64, device="cuda")
+        d_share = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+        d_ring = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+        d_wire = torch.full(((nbytes + 7) // 8 + 1,), -1, dtype=torch.int64, device="cuda")
+        d_wire2 = torch.full(((nb2 + 7) // 8 + 1,), -1, dtype=torch.int64, device="cuda")
+        L.check(lib.mmh_bn_alice_prepare(g.handle, L.dptr(d_rcm), L.dptr(d_rcm2), u2(delta), u2(S), u2(S2), gid0, L.dptr(d_x),
+                                         n, bw, shift, L.dptr(d_sc), key, sid, L.dptr(d_pts3),
+                                         L.dptr(d_share) if want_share else None, L.dptr(d_ring), L.dptr(d_wire),
+                                         L.dptr(d_wire2), None))
+        pts3 = host(d_pts3)
+        assert np.array_equal(pts3[0], ref_in) and np.array_equal(pts3[1], ref_sc) and np.array_equal(pts3[2], ref_r)
+        if want_share:
+            assert np.array_equal(host(d_share), ref_share)
+        assert np.array_equal(host(d_ring), ref_ring[shift]), f"shift {shift}"
+        gw = d_wire.cpu().numpy().view(np.uint8)
+        assert np.array_equal(gw[:nbytes], wire[:nbytes]) and (gw[nbytes:] == 0xFF).all()
+        gw = d_wire2.cpu().numpy().view(np.uint8)
+        assert np.array_equal(gw[:nb2], ref_wire2[shift]) and (gw[nb2:] == 0xFF).all()
     d_out = torch.full((bn.n_ct, 2, N), -1, dtype=torch.int64, device="cuda")
     L.check(lib.mmh_bn_alice_finish(g.handle, L.dptr(d_cts), L.dptr(d_pts3), n, L.dptr(d_out), None))
     assert np.array_equal(host(d_out), ref_out.reshape(bn.n_ct, 2, N))
