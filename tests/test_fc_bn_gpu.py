@@ -310,7 +310,7 @@ def test_network_bn_layer_bit_exact(mm, n):
     assert d.min() >= 0 and d.max() <= 2 and int((d == 2).sum()) <= 2
 
 
-@pytest.mark.parametrize("n", [5, 1000, 4096, 3 * 4096 + 77, 7 * 7 * 1024])
+@pytest.mark.parametrize("n", [5, 1000, 4096, 3 * 4096 + 77, 7 * 7 * 1024, 56 * 56 * 256])
 def test_alice_bn_layer_in_two_calls(mm, n):
     """ALICE's side of a batch-norm layer as mmh_bn_alice_prepare + mmh_bn_alice_finish (five launches): the three
     plaintext batches, her share, her ring share of the result, every byte of both COTs' wires and the result
