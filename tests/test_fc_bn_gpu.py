@@ -388,6 +388,15 @@ def test_alice_bn_layer_in_two_calls(mm, n):
         L.check(lib.mmh_bn_alice_finish(g.handle, None, L.dptr(d_pts3), n, L.dptr(d_out), None))
 
 
+def test_alice_bn_layer_in_two_calls_n8192(mm, monkeypatch):
+    """the same on an N = 8192 context (the LOGN = 13 forms of bn_front_kernel and of the transforms; not a configuration
+    the reference's bn runs, cheetah-api.cpp:150-162, but one the entry points accept)"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "N", 8192)
+    test_alice_bn_layer_in_two_calls(mm, 2 * 8192 + 77)
+    test_alice_bn_layer_in_two_calls(mm, 100)
+
+
 def test_bole_full_size_identity(mm):
     """bole_test flags 1 1 size: 2^20 elements, l=32, |x|,|y| < 2^12 (tests/bole_test.cpp:78,98,568)"""
     import torch
