@@ -1055,15 +1055,41 @@ __global__ __launch_bounds__(512) void pw_mfma_kernel(const uint4 *__restrict__ 
 // step k.  Same digits, same i32 sums, same PwRed epilogue as pw_mfma_kernel: the same bits.
 // The launch also does what the digit launch did for a call from raw tensors: folds the weight pass's flag words and
 // evaluates the zero-filter rule (workgroup 0).
-constexpr int kPwNarrowLds = 2 * (2048 + 3 * 128) * 16;   // 76 KiB: two workgroups per compute unit
+constexpr int kPwNarrowLds = 2 * (2048 + 3 * 128) * 16;   // 76 KiB
+// The pk-encryptions of zero of a drawing call (ntt_zero_unit12: u drawn, transformed, multiplied by pk_j, transformed
+// back) depend on nothing else in the call and only the tail reads them.  In the front launch they were its longest
+// workgroups by far -- two transforms in a row, ~16 us, beside ~10 us of image and weight work.  Here they RIDE in the
+// product launch instead: its first `wgs` workgroups make one ciphertext's two components each (lanes 0-255 component
+// 0, lanes 256-511 component 1, each on its own half of the LDS allocation) beside products that take 20-40 us.
+// (Tried and dropped: the same in the digit image's launch and in pw_mfma_kernel's -- those launches are shorter than
+// the riders, or their persistent workgroups already take every compute unit: EXPERIMENTS.md.)
+struct ZeroRide {
+  unsigned wgs;            // output ciphertexts = riding workgroups (0: nothing rides)
+  const u64 *pk;           // pk at the last level [2][N], NTT form
+  u64 *zero;               // [wgs][2][N]
+  const ulonglong2 *tables;
+  ChaChaKey key;           // the ternary stream of the draw
+  u64 sid, first_tile;
+};
 __global__ __launch_bounds__(512, 2) void pw_narrow_kernel(const u64 *__restrict__ image, const PwChannel *__restrict__ chan,
                                                         const int *__restrict__ live, const uint4 *__restrict__ w8,
                                                         const u32 *__restrict__ flag, u64 *__restrict__ acc, int M,
                                                         int KC, size_t S, int logN, const DevMod *__restrict__ mods,
                                                         const u64 *__restrict__ wl, int Mpad, int Cpad, PwLift lift,
-                                                        PwFold fold, u32 *__restrict__ zero_filter, int skip7) {
+                                                        PwFold fold, u32 *__restrict__ zero_filter, int skip7,
+                                                        ZeroRide zr) {
   extern __shared__ uint4 pwn_lds[];
   __shared__ u32 s_flag;
+  if (blockIdx.x < zr.wgs) {   // (uniform over the workgroup)
+    const unsigned j = threadIdx.x >> 8;
+    NttSource usrc{};
+    usrc.key = zr.key, usrc.sid = zr.sid, usrc.first_tile = zr.first_tile;
+    ntt_zero_unit12<true>(blockIdx.x, mods[0], zr.tables, usrc, zr.pk + ((size_t)j << 12),
+                          zr.zero + (((size_t)blockIdx.x * 2 + j) << 12),
+                          reinterpret_cast<u64 *>(pwn_lds) + j * (lds_bytes<12>() / 8), (int)(threadIdx.x & 255));
+    return;
+  }
+  const unsigned bid = blockIdx.x - zr.wgs;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (fold.wflag) {   // (a call from raw tensors: the weight pass left one word of flag bits per workgroup)
@@ -1072,9 +1098,9 @@ __global__ __launch_bounds__(512, 2) void pw_narrow_kernel(const u64 *__restrict
     const int b0 = __syncthreads_or((int)(bits & 1u)), b1 = __syncthreads_or((int)(bits & 2u));
     if (tid == 0) {
       s_flag = (b0 ? 1u : 0u) | (b1 ? 2u : 0u);
-      if (blockIdx.x == 0) *fold.flag_out = s_flag;
+      if (bid == 0) *fold.flag_out = s_flag;
     }
-    if (fold.anymap && blockIdx.x == 0)   // conv2DOneFilter :573-580: some filter all zero mod t?
+    if (fold.anymap && bid == 0)   // conv2DOneFilter :573-580: some filter all zero mod t?
       for (int m = 0; m < M; ++m) {
         int any = 0;
         for (int kg = tid; kg < fold.KG; kg += 512) any |= fold.anymap[(size_t)kg * fold.Mpad128 + m];
@@ -1085,7 +1111,7 @@ __global__ __launch_bounds__(512, 2) void pw_narrow_kernel(const u64 *__restrict
   }
   __syncthreads();
   const u32 fl = s_flag;
-  const size_t c0 = (size_t)live[blockIdx.x] * 64;   // first column of the tile: (window, c0/c1, limb, i)
+  const size_t c0 = (size_t)live[bid] * 64;   // first column of the tile: (window, c0/c1, limb, i)
   const int N = 1 << logN;
   const size_t cols = S * 4 * N;
   const int pl = (int)((c0 >> logN) & 3);
@@ -1370,11 +1396,25 @@ static int pointwise_weights(const mmh_conv_plan *p, const u64 *d_filters_raw, c
   return MMH_OK;
 }
 // acc[m*S + sp] ([2][2][N] each, coefficient form) for all filters from the coefficient-form image
+// Whether a fresh front-launch call's encryptions of zero ride in the product launch: the one-launch narrow kernel at
+// N = 4096 (pointwise_product takes it under the same condition), and only while every workgroup of that launch gets a
+// compute unit of its own -- with more tiles than that the riders delay products (128 -> 32 3x3 at 56x56, 400 tiles:
+// +11 %) where at 28x28 and below the call gains 12-16 %.  MMH_ZERO_RIDE=0 keeps them in the front launch, =1 lets
+// them ride whatever the grid.
+static bool pw_zero_rides(const mmh_conv_plan *p, bool switched) {
+  const char *e = getenv("MMH_ZERO_RIDE");
+  if (e && e[0] == '0') return false;
+  static_assert(2 * lds_bytes<12>() <= (size_t)kPwNarrowLds, "two transform images in the narrow kernel's LDS");
+  if (p->ctx->logN != 12 || !pw_mfma_enabled(p->ctx) || !pw_narrow_ok(p) || switched) return false;
+  return e ? true : (int)(p->pw_live_tiles + p->n_out) <= p->ctx->n_cu;
+}
 static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32 *wp, const u64 *wl, const uint8_t *w8,
                              const u32 *flag, u64 *acc, hipStream_t s, bool fill_dead, int form = -1,
                              const u32 *nzmap = nullptr, u32 *zero_filter = nullptr, const PwFold *fold = nullptr,
-                             void *verdict_event = nullptr, const u64 *raw_filters = nullptr, bool switched = false) {
+                             void *verdict_event = nullptr, const u64 *raw_filters = nullptr, bool switched = false,
+                             const ZeroRide *ride = nullptr) {
   // switched: acc receives the MOD-SWITCHED product, [M][S][2][N] at the last level (pw_switched_ok() must hold)
+  // ride: encryptions of zero to make in the narrow kernel's launch (the caller has checked pw_zero_rides())
   const mmh_ctx *ctx = p->ctx;
   const size_t N = ctx->N, S = p->n_spatial, cols = S * 4 * N;
   MMH_REQUIRE(!switched || (pw_switched_ok(ctx) && form != 1 && !fill_dead), MMH_ERR_INTERNAL);
@@ -1394,10 +1434,11 @@ static int pointwise_product(const mmh_conv_plan *p, const u64 *image, const u32
     const int skip7n = ((ctx->q[0] >> 54) == 0 ? 1 : 0) | ((ctx->q[1] >> 54) == 0 ? 2 : 0);
     if (pw_narrow_ok(p) && !nzmap && !switched) {   // one launch, no digit image (the non-front weight pass keeps the image)
       if (fill_dead) MMH_HIP(hipMemsetAsync(acc, 0, (size_t)z.M * cols * 8, s));
-      hipLaunchKernelGGL(pw_narrow_kernel, dim3((unsigned)n_live), dim3(512), kPwNarrowLds, s, image, p->d_pw_chan, p->d_pw_live,
-                         (const uint4 *)w8, flag, acc, z.M, KC, S, ctx->logN, ctx->d_mods, wl, z.Mpad, z.Cpad,
+      const ZeroRide zr = ride ? *ride : ZeroRide{};
+      hipLaunchKernelGGL(pw_narrow_kernel, dim3((unsigned)n_live + zr.wgs), dim3(512), kPwNarrowLds, s, image, p->d_pw_chan,
+                         p->d_pw_live, (const uint4 *)w8, flag, acc, z.M, KC, S, ctx->logN, ctx->d_mods, wl, z.Mpad, z.Cpad,
                          PwLift{raw_filters, z.C, ctx->bfv.t, ctx->bfv.thr},
-                         fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0}, zero_filter, skip7n);
+                         fold ? *fold : PwFold{nullptr, 0, nullptr, nullptr, 0, 0}, zero_filter, skip7n, zr);
       MMH_HIP(hipGetLastError());
       if (verdict_event) MMH_HIP(hipEventRecord((hipEvent_t)verdict_event, s));   // the zero-filter word is final here
       return MMH_OK;
@@ -1839,6 +1880,11 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   // (FrontDraw); elsewhere one sampling launch makes the arrays here and the call goes on as if they had been passed
   const bool draw_in_front = draw_key && front && ctx->h_mods[0].fold_c != 0 && !ctx->h_mods[0].f64;
   const bool draw_zero = draw_in_front && ctx->logN == 12 && p->n_out <= reshare_split_max();
+  // The approximate tail's first act on the accumulator is divide_and_round_q_last: where the matrix-core product
+  // runs, its items own both limbs and write the switched value, one word per coefficient instead of two
+  const bool sw_acc = !exact && direct && pw_switched_ok(ctx) && (prepared ? prepared->form != 1 : front) && pw_paired_pays(p);
+  const bool ride_zero = draw_zero && !prepared && pw_zero_rides(p, sw_acc);   // made in the product launch instead
+  ZeroRide ride{};
   if (draw_key) {
     grab(&dr_e1, p->n_out * N * 8);
     grab(&dr_mask, p->n_out * N * 8);
@@ -1866,7 +1912,7 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
       // u's transform rides along when the tail will want it (approximate build, q0 of the folding shape)
       const bool with_u = !exact && !d_zero_enc && ctx->h_mods[0].fold_c != 0 && !ctx->h_mods[0].f64;
       if (with_u && !draw_zero) grab(&u_ntt, p->n_out * N * 8);
-      const unsigned n_u = with_u && !rc ? (unsigned)p->n_out * (draw_zero ? 2u : 1u) : 0;
+      const unsigned n_u = with_u && !rc && !ride_zero ? (unsigned)p->n_out * (draw_zero ? 2u : 1u) : 0;
       NttSource usrc{};
       usrc.p = reinterpret_cast<const u64 *>(d_u);
       FrontDraw dr{};
@@ -1878,6 +1924,8 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
         auto lo = [&](int per) { return (unsigned)(first / (256 * (size_t)per)); };
         auto cnt = [&](int per) { return (unsigned)((first + total + 256 * (size_t)per - 1) / (256 * (size_t)per)) - lo(per); };
         dr.mode = draw_zero ? 2 : 1, dr.pk = d_pk_ntt_last, dr.zero = (u64 *)dr_zero;
+        if (ride_zero && with_u && !rc)
+          ride = ZeroRide{(unsigned)p->n_out, d_pk_ntt_last, (u64 *)dr_zero, ctx->d_tables, usrc.key, usrc.sid, usrc.first_tile};
         dr.e1 = (int64_t *)dr_e1, dr.mask = (u64 *)dr_mask;
         dr.n_e = cnt(kNoisePerBlock), dr.n_m = cnt(kUniformPerBlock), dr.lo_e = lo(kNoisePerBlock), dr.lo_m = lo(kUniformPerBlock);
         dr.first = first, dr.total = total;
@@ -1932,16 +1980,13 @@ static int conv_server_impl(const mmh_conv_plan *p, const uint64_t *d_in_cts, co
   if (!rc && !direct) rc = ntt_dispatch(ctx, false, (u64 *)image, p->n_in * 2, 2, 0, s);
   // multiply_plain's lift + NTT of every filter polynomial, from the plaintexts or straight from the taps
   const u64 *filt_ntt = prepared ? prepared->f_ntt : (const u64 *)f_ntt;
-  // The approximate tail's first act on the accumulator is divide_and_round_q_last: where the matrix-core product
-  // runs, its items own both limbs and write the switched value, one word per coefficient instead of two
-  const bool sw_acc = !exact && direct && pw_switched_ok(ctx) && (prepared ? prepared->form != 1 : front) && pw_paired_pays(p);
   if (!rc && direct && prepared)
     rc = pointwise_product(p, (const u64 *)image, prepared->wp, prepared->wl, prepared->w8, prepared->flag,
                            (u64 *)acc, s, exact, prepared->form, nullptr, nullptr, nullptr, nullptr, nullptr, sw_acc);
   if (!rc && front && !prepared)
     rc = pointwise_product(p, (const u64 *)image, (const u32 *)wp, (const u64 *)wl, (const uint8_t *)w8,
                            (const u32 *)flag_word, (u64 *)acc, s, exact, -1, nullptr, d_zero_filter, &fold,
-                           nz_inline ? verdict_event : nullptr, d_filters_raw, sw_acc);
+                           nz_inline ? verdict_event : nullptr, d_filters_raw, sw_acc, ride.wgs ? &ride : nullptr);
   if (!rc && direct && !prepared && !front)
     rc = pointwise_mac(p, (const u64 *)image, d_filters_raw, d_filter_pts, (u64 *)acc, s, exact, (u32 *)flag_word);
   if (!rc && !direct && !prepared && d_filters_raw)

@@ -233,11 +233,12 @@ struct NttSource {
 };
 
 // The EA = N/256 stride-256 coefficients of thread t, from wherever the transform reads them.
+// (t: the lane's index in its transform workgroup of 256 -- threadIdx.x, except where two transforms share a wider
+// workgroup)
 template <int LOGN, int SRC>
 __device__ __forceinline__ void load_source(u32 unit, u64 (&x)[1 << (LOGN - 8)], const u64 *__restrict__ a,
-                                            const DevMod &M, const NttSource &src, int limbs, u64 *lds) {
+                                            const DevMod &M, const NttSource &src, int limbs, u64 *lds, int t) {
   constexpr int EA = 1 << (LOGN - 8);
-  const int t = threadIdx.x;
   if (SRC == SRC_CT_PLAIN) {
     const u32 poly = unit / limbs, l = unit % limbs;
     const u64 *__restrict__ c = src.p + ((size_t)unit << LOGN);
@@ -299,6 +300,12 @@ __device__ __forceinline__ void load_source(u32 unit, u64 (&x)[1 << (LOGN - 8)],
 #pragma unroll
     for (int k = 0; k < EA; ++k) x[k] = a[k * 256 + t];
   }
+}
+
+template <int LOGN, int SRC>
+__device__ __forceinline__ void load_source(u32 unit, u64 (&x)[1 << (LOGN - 8)], const u64 *__restrict__ a,
+                                            const DevMod &M, const NttSource &src, int limbs, u64 *lds) {
+  load_source<LOGN, SRC>(unit, x, a, M, src, limbs, lds, (int)threadIdx.x);
 }
 
 template <int LOGN>
@@ -429,12 +436,13 @@ __device__ __forceinline__ void ntt_fwd_unit(u32 unit, u64 *__restrict__ data, c
 // ONE workgroup, nothing but the result written.  The forward transform's last pass and the inverse transform's first
 // work on the same 16 consecutive coefficients of a lane, so the product with the key happens in registers between
 // them.  Same canonical values as SRC_TERNARY -> ntt_inv_kernel<PROD>: out = INTT(NTT(u) (.) key).
+// `t` is the lane's index among the unit's 256 (every __syncthreads() below is reached by all lanes of the workgroup: a
+// 512-thread workgroup runs two units side by side, each on its own `lds`).
 template <bool FOLD>
 __device__ __forceinline__ void ntt_zero_unit12(u32 poly, const DevMod &M, const ulonglong2 *__restrict__ tables,
                                                 const NttSource &src, const u64 *__restrict__ key,
-                                                u64 *__restrict__ out, u64 *lds) {
+                                                u64 *__restrict__ out, u64 *lds, int t) {
   constexpr int LOGN = 12, N = 1 << LOGN;
-  const int t = threadIdx.x;
   const ulonglong2 *__restrict__ tw = tables + M.tw_offset, *__restrict__ twi = tw + N;
   const Reducer<FOLD> rd(M);
   const u64 nq = M.nq;
@@ -442,7 +450,7 @@ __device__ __forceinline__ void ntt_zero_unit12(u32 poly, const DevMod &M, const
     ulonglong2 wB[15];
     {
       u64 x[16];
-      load_source<LOGN, SRC_TERNARY>(poly, x, nullptr, M, src, 1, lds);
+      load_source<LOGN, SRC_TERNARY>(poly, x, nullptr, M, src, 1, lds, t);
       ulonglong2 wA[15];
       load_twiddles<4, 0>(tw, 0, wA);
       load_twiddles<4, 4>(tw, t >> 4, wB);
@@ -508,6 +516,13 @@ __device__ __forceinline__ void ntt_zero_unit12(u32 poly, const DevMod &M, const
 #pragma unroll
     for (int k = 0; k < 16; ++k) out[k * 256 + t] = csub64(csub64(mul_shoup_lazy4(x[k], ninv, ninv_sh, nq), rd.q2), rd.q);
   }
+}
+
+template <bool FOLD>
+__device__ __forceinline__ void ntt_zero_unit12(u32 poly, const DevMod &M, const ulonglong2 *__restrict__ tables,
+                                                const NttSource &src, const u64 *__restrict__ key,
+                                                u64 *__restrict__ out, u64 *lds) {
+  ntt_zero_unit12<FOLD>(poly, M, tables, src, key, out, lds, (int)threadIdx.x);
 }
 
 template <int LOGN>

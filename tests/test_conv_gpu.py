@@ -458,6 +458,14 @@ def test_conv_call_that_draws_its_own_randomness(mm, monkeypatch, ishape, fhw, M
     got_out, got_share = server.conv2DSSFromTensors(cts, share, filters, meta, b)
     assert np.array_equal(host(got_out), host(ref_out)) and np.array_equal(host(got_share), host(ref_share))
     assert b.next_stream == a.next_stream
+    if route == "1n":   # the encryptions of zero made in the front launch / riding in the narrow kernel's, whatever its grid
+        for ride in ("0", "1"):
+            monkeypatch.setenv("MMH_ZERO_RIDE", ride)
+            c = Sampler(g, key)
+            c.words(5)
+            got_out, got_share = server.conv2DSSFromTensors(cts, share, filters, meta, c)
+            assert np.array_equal(host(got_out), host(ref_out)) and np.array_equal(host(got_share), host(ref_share)), ride
+        monkeypatch.delenv("MMH_ZERO_RIDE")
     # deferred verdict form
     got_out, got_share = server.conv2DSSFromTensors(cts, share, filters, meta, Sampler(g, key), defer_verdict=True)
     import torch
