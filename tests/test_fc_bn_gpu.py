@@ -386,6 +386,15 @@ def test_alice_bn_layer_in_two_calls(mm, n):
     assert np.array_equal(host(d_out), ref_out.reshape(bn.n_ct, 2, N))
     with pytest.raises(mm.MMHError):
         L.check(lib.mmh_bn_alice_finish(g.handle, None, L.dptr(d_pts3), n, L.dptr(d_out), None))
+    for bad in (dict(bw=1), dict(shift=64), dict(ring=None), dict(n=0)):   # argument checks: nothing is launched
+        with pytest.raises(mm.MMHError):
+            L.check(lib.mmh_bn_alice_prepare(g.handle, L.dptr(d_rcm), L.dptr(d_rcm2), u2(delta), u2(S), u2(S2), gid0,
+                                             L.dptr(d_x), bad.get("n", n), bad.get("bw", bw), bad.get("shift", k), L.dptr(d_sc),
+                                             key, sid, L.dptr(d_pts3), None, bad.get("ring", L.dptr(d_ring)), L.dptr(d_wire),
+                                             L.dptr(d_wire2), None))
+    plain = mm.Context(N, (60, 49), 1 << 37)   # no batching under t = 2^37 (setUp_Field: "invalid SIMD modulus")
+    with pytest.raises(mm.MMHError):
+        L.check(lib.mmh_bn_alice_finish(plain.handle, L.dptr(d_cts), L.dptr(d_pts3), n, L.dptr(d_out), None))
 
 
 def test_alice_bn_layer_in_two_calls_n8192(mm, monkeypatch):
