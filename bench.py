@@ -418,7 +418,9 @@ class NetworkLegs:
     them per inference: CheetahLinear::conv2d (cheetah-api.cpp:417-445: encodeFilters, encodeImage, conv2DSS), ::fc
     (:343-373) and, for every live batch-norm, ElemWiseActModelVectorMult (library_fixed_uniform_cheetah.cpp:567-600):
     Ring2Field on her share (pre step, COT post-processing as the sender, post step fused into encodeVector),
-    CheetahLinear::bn (:560-602: encodeScales, bn + addMask) and Field2Ring_with_Truncate on her output share.
+    CheetahLinear::bn (:560-602: encodeScales, bn + addMask) and Field2Ring_with_Truncate on her output share -- the same
+    work in five launches (mmh_bn_alice_prepare / mmh_bn_alice_finish: her share is -r, so its conversion needs no
+    ciphertext and runs beside Ring2Field; bit for bit the step-by-step calls, tests/test_fc_bn_gpu.py).
     EVERY call draws its own randomness on the device inside the call (u, e1 and the mask for each output ciphertext
     as conv2DSS / matVecMul do at hom_conv2d_ss.cc:275-340,180-223; addMask's r, hom_bn_ss.cc:329-334)."""
 
